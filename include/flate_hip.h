@@ -1,0 +1,126 @@
+/*
+ * flate_hip.h -- C ABI of libflate_hip.so: the MI355X (gfx950) batch engine for
+ * the deflate-fast encode path (and batch inflate) of gmlewis/moonbit-flate.
+ *
+ * The reference has no FFI of its own (pure MoonBit); the
+ * natural seam is Compressor::enc_speed (reference deflate.mbt:236-277), which
+ * takes window[:window_end] plus the persistent DeflateFast {table, cur} and
+ * appends DEFLATE bytes to the sink.  This ABI generalises that seam to N
+ * independent streams ("fresh Writer per stream"): for every stream i the bytes
+ * produced equal  Writer::new(buf) ; write(in[in_off[i]:in_off[i+1]]) ; close()
+ * (reference writer.mbt:10,45,53 -> deflate.mbt:280-294,157-183), bit for bit.
+ *
+ * Plain pointers and sizes only; no torch / C++ types.  One ctx per host thread;
+ * calls on distinct contexts are independent.  The caller owns every buffer; the
+ * library retains no pointer after a call returns.  Errors: 0 = ok, negative enum
+ * below, never abort (the reference's sticky IOError / abort() become codes).
+ */
+#ifndef FLATE_HIP_H
+#define FLATE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct flate_hip_ctx flate_hip_ctx;
+
+/* error codes */
+#define FLATE_HIP_OK 0
+#define FLATE_HIP_E_INVALID (-1)        /* bad argument                               */
+#define FLATE_HIP_E_OUT_TOO_SMALL (-2)  /* out_cap / slot too small                    */
+#define FLATE_HIP_E_HIP (-3)            /* HIP runtime failure (see strerror)         */
+#define FLATE_HIP_E_CORRUPT (-4)        /* inflate: corrupt_input_error (inflate.mbt:38) */
+#define FLATE_HIP_E_NO_DEVICE (-5)      /* no usable GPU: the engine has no CPU path  */
+#define FLATE_HIP_E_TOO_LARGE (-6)      /* stream >= 2 GiB - 128 KiB (buffer_reset,
+                                           deflate-fast.mbt:55: shift_offsets not built) */
+#define FLATE_HIP_E_UNEXPECTED_EOF (-7) /* inflate: err_unexpected_eof (inflate.mbt:781) */
+
+/* flags */
+#define FLATE_HIP_DEVICE_PTRS 0x1u /* in/out (and tokens/recs) are device pointers; offset
+                                      tables are always host arrays                     */
+#define FLATE_HIP_COMPAT_GO 0x2u   /* Go 1.23.1 semantics: fixes divergences D1
+                                      (deflate-fast.mbt:157,310) and D2
+                                      (huffman-bit-writer.mbt:527,780); default is the
+                                      reference's own (MoonBit) behaviour                */
+#define FLATE_HIP_LZ_SERIAL 0x4u   /* debug: single-lane match finder kernel            */
+
+/* -- lifecycle ------------------------------------------------------------------
+ * replaces: Writer::new (writer.mbt:10) / Compressor::new (deflate.mbt:81) state
+ * allocation; one ctx holds the scratch for any number of streams. */
+int flate_hip_init(int device, flate_hip_ctx **ctx);
+void flate_hip_destroy(flate_hip_ctx *ctx);
+/* Run on the caller's HIP stream (hipStream_t passed as void*), e.g. torch's
+ * current stream; NULL = the ctx's own stream. */
+int flate_hip_set_stream(flate_hip_ctx *ctx, void *hip_stream);
+const char *flate_hip_strerror(int code);
+/* Text of the last HIP runtime error seen by this ctx ("" if none). */
+const char *flate_hip_last_hip_error(const flate_hip_ctx *ctx);
+
+/* -- encode ---------------------------------------------------------------------
+ * Upper bound of the compressed size of one stream of in_len bytes. */
+size_t flate_hip_deflate_bound(size_t in_len);
+
+/* replaces: Writer::write + Writer::close (writer.mbt:45,53; deflate.mbt:280,157)
+ * for n_streams independent streams.  in_off has n_streams+1 entries (host);
+ * stream i is in[in_off[i] .. in_off[i+1]).  On return out holds the streams back
+ * to back and out_off[0..n_streams] (host, written) their offsets. */
+int flate_hip_deflate_fast_batch(flate_hip_ctx *ctx, const uint8_t *in,
+                                 const uint64_t *in_off, uint32_t n_streams,
+                                 uint8_t *out, uint64_t out_cap, uint64_t *out_off,
+                                 uint32_t flags);
+
+/* Match-finder only (replaces DeflateFast::encode, deflate-fast.mbt:123-270), for
+ * token-stream parity tests.  A stream is cut into LZ77 chunks exactly as
+ * Compressor::enc_speed does (every full 65535-byte window, plus a final partial
+ * window of >= 128 bytes).  For chunk c (global index, stream order):
+ *   chunk_nmatch[c] matches, records at recs[2*chunk_rec_off[c] ...], each record
+ *   = { position of the match start inside the chunk, token as token.mbt:76 }.
+ * Literal tokens are implied: every byte not covered by a match (token.mbt:69).
+ * Call with recs == NULL to query *n_chunks and *n_recs_cap. */
+int flate_hip_lz77_matches(flate_hip_ctx *ctx, const uint8_t *in, const uint64_t *in_off,
+                           uint32_t n_streams, uint32_t flags, uint32_t *n_chunks,
+                           uint64_t *n_recs_cap, uint32_t *chunk_nmatch,
+                           uint64_t *chunk_rec_off, uint32_t *recs);
+
+/* -- decode ---------------------------------------------------------------------
+ * replaces: &Reader::new + read to EOF (inflate.mbt:305,382) for n_streams
+ * independent DEFLATE streams.  Stream i is in[in_off[i]..in_off[i+1]); its output
+ * goes to out[out_off[i] .. out_off[i+1]) (capacity); out_len[i] = bytes produced;
+ * status[i] = 0 or a negative code; err_off[i] = input offset reported by
+ * corrupt_input_error (or -1). Returns the first non-zero status. */
+int flate_hip_inflate_batch(flate_hip_ctx *ctx, const uint8_t *in, const uint64_t *in_off,
+                            uint32_t n_streams, uint8_t *out, const uint64_t *out_off,
+                            uint64_t *out_len, int32_t *status, int64_t *err_off,
+                            uint32_t flags);
+
+/* -- measurement ----------------------------------------------------------------
+ * With profiling on, every kernel launch of the next call is bracketed by HIP
+ * events on the launch stream; flate_hip_last_timing returns the per-stage
+ * milliseconds of the last call (stage names via flate_hip_stage_name). */
+#define FLATE_HIP_STAGE_LZ77 0
+#define FLATE_HIP_STAGE_HUFF_PACK 1
+#define FLATE_HIP_STAGE_COMPACT 2
+#define FLATE_HIP_STAGE_INFLATE 3
+#define FLATE_HIP_STAGE_COUNT 4
+int flate_hip_set_profiling(flate_hip_ctx *ctx, int on);
+int flate_hip_last_timing(flate_hip_ctx *ctx, float *ms, int n);
+const char *flate_hip_stage_name(int stage);
+
+/* -- synthetic workloads (host side, no GPU needed) --------------------------------
+ * Bit-reproducible generators for the benchmark inputs of BASELINE.md section 3.
+ * Fills n_streams streams of stream_len bytes each, back to back, into out (host). */
+#define FLATE_SYNTH_RAMP 0 /* byte[i] = i & 127 (deflate-fast_test.mbt:15-24) */
+#define FLATE_SYNTH_TEXT 1 /* Zipf word text, the headline workload          */
+#define FLATE_SYNTH_RAND 2 /* uniform random bytes                            */
+#define FLATE_SYNTH_ZERO 3 /* all zero                                        */
+int flate_hip_synth_fill(int kind, uint64_t seed, uint64_t first_stream,
+                         uint32_t n_streams, uint64_t stream_len, uint8_t *out,
+                         int nthreads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,63 @@
+"""ctypes loader of libflate_hip.so.  There is no fallback: a missing library is an error."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libflate_hip.so")
+
+# every symbol include/flate_hip.h declares
+EXPORTS = [
+    "flate_hip_init", "flate_hip_destroy", "flate_hip_set_stream", "flate_hip_strerror",
+    "flate_hip_last_hip_error", "flate_hip_deflate_bound", "flate_hip_deflate_fast_batch",
+    "flate_hip_lz77_matches", "flate_hip_inflate_batch", "flate_hip_set_profiling",
+    "flate_hip_last_timing", "flate_hip_stage_name", "flate_hip_synth_fill",
+]
+
+_lib = None
+
+
+class FlateLibraryMissing(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FlateLibraryMissing(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). This package has no CPU fallback." % LIB_PATH)
+    try:
+        import torch  # noqa: F401  (load torch's HIP runtime first so both share one libamdhip64)
+    except Exception:
+        pass
+    L = C.CDLL(LIB_PATH)
+    vp, u64p = C.c_void_p, C.POINTER(C.c_uint64)
+    L.flate_hip_init.argtypes = [C.c_int, C.POINTER(vp)]
+    L.flate_hip_init.restype = C.c_int
+    L.flate_hip_destroy.argtypes = [vp]
+    L.flate_hip_destroy.restype = None
+    L.flate_hip_set_stream.argtypes = [vp, vp]
+    L.flate_hip_strerror.argtypes = [C.c_int]
+    L.flate_hip_strerror.restype = C.c_char_p
+    L.flate_hip_last_hip_error.argtypes = [vp]
+    L.flate_hip_last_hip_error.restype = C.c_char_p
+    L.flate_hip_deflate_bound.argtypes = [C.c_size_t]
+    L.flate_hip_deflate_bound.restype = C.c_size_t
+    L.flate_hip_deflate_fast_batch.argtypes = [vp, vp, vp, C.c_uint32, vp, C.c_uint64, vp, C.c_uint32]
+    L.flate_hip_deflate_fast_batch.restype = C.c_int
+    L.flate_hip_lz77_matches.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32,
+                                         C.POINTER(C.c_uint32), u64p, vp, vp, vp]
+    L.flate_hip_lz77_matches.restype = C.c_int
+    L.flate_hip_inflate_batch.argtypes = [vp, vp, vp, C.c_uint32, vp, vp, vp, vp, vp, C.c_uint32]
+    L.flate_hip_inflate_batch.restype = C.c_int
+    L.flate_hip_set_profiling.argtypes = [vp, C.c_int]
+    L.flate_hip_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
+    L.flate_hip_stage_name.argtypes = [C.c_int]
+    L.flate_hip_stage_name.restype = C.c_char_p
+    L.flate_hip_synth_fill.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64,
+                                       vp, C.c_int]
+    L.flate_hip_synth_fill.restype = C.c_int
+    _lib = L
+    return L

@@ -1,0 +1,441 @@
+// flate_api.hip -- C ABI of libflate_hip.so (see include/flate_hip.h).
+//
+// Host-side driver: plans the chunking exactly as Compressor::write / enc_speed /
+// close stage their 65535-byte window (reference deflate.mbt:222-294,157-183), owns
+// the HBM scratch (match records, output slots, index arrays) and launches the
+// kernels on one HIP stream.  There is no CPU compression path in this library.
+#include "flate_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "flate_kernels.h"
+
+using namespace flate;
+
+namespace {
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+};
+
+}  // namespace
+
+struct flate_hip_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string hip_err;
+  bool profiling = false;
+  float stage_ms[FLATE_HIP_STAGE_COUNT] = {0, 0, 0, 0};
+  hipEvent_t ev[2 * FLATE_HIP_STAGE_COUNT] = {};
+  // persistent device data
+  DevBuf scan_tab;
+  int scan_len = 0;
+  // grow-only scratch
+  DevBuf d_in, d_out, d_in_off, d_chunk_base, d_ids16, d_ids32, d_matches, d_nmatch, d_ntok;
+  DevBuf d_slots, d_slot_off, d_out_len, d_out_off, d_status;
+  DevBuf d_istatus, d_ierr;
+};
+
+namespace {
+
+#define HIP_TRY(ctx, expr)                                                         \
+  do {                                                                             \
+    hipError_t e_ = (expr);                                                        \
+    if (e_ != hipSuccess) {                                                        \
+      (ctx)->hip_err = std::string(#expr) + ": " + hipGetErrorString(e_);          \
+      return FLATE_HIP_E_HIP;                                                      \
+    }                                                                              \
+  } while (0)
+
+int ensure(flate_hip_ctx *c, DevBuf &b, size_t bytes) {
+  if (bytes <= b.cap) return FLATE_HIP_OK;
+  if (b.p) HIP_TRY(c, hipFree(b.p));
+  b.p = nullptr;
+  b.cap = 0;
+  size_t want = bytes + (bytes >> 3) + 256;
+  HIP_TRY(c, hipMalloc(&b.p, want));
+  b.cap = want;
+  return FLATE_HIP_OK;
+}
+
+void release(DevBuf &b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+}
+
+// Probe offsets of the skip heuristic (deflate-fast.mbt:178-187) from skip = 32.
+std::vector<uint16_t> make_scan_table() {
+  std::vector<uint16_t> t;
+  uint32_t skip = 32, pos = 0;
+  while (pos <= 65535) {
+    t.push_back((uint16_t)pos);
+    uint32_t step = skip >> 5;
+    pos += step;
+    skip += step;
+  }
+  t.push_back(65535);  // sentinel: never a legal probe
+  return t;
+}
+
+struct StagePlan {
+  uint32_t n_streams = 0;
+  std::vector<uint32_t> chunk_base;  // n+1
+  std::vector<uint32_t> ids16, ids32;
+  std::vector<uint64_t> slot_off;  // n+1
+  uint32_t n_chunks = 0;
+};
+
+int make_plan(const uint64_t *in_off, uint32_t n, StagePlan &pl) {
+  pl.n_streams = n;
+  pl.chunk_base.resize((size_t)n + 1);
+  pl.slot_off.resize((size_t)n + 1);
+  uint64_t chunks = 0, slot = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (in_off[i + 1] < in_off[i]) return FLATE_HIP_E_INVALID;
+    const uint64_t len = in_off[i + 1] - in_off[i];
+    if (len >= 0x7ffe0000ull) return FLATE_HIP_E_TOO_LARGE;
+    const uint64_t full = len / kMaxStoreBlockSize, r = len % kMaxStoreBlockSize;
+    const uint64_t nch = full + (r >= (uint64_t)kSmallLzMin ? 1 : 0);
+    pl.chunk_base[i] = (uint32_t)chunks;
+    pl.slot_off[i] = slot;
+    if (nch == 1) {
+      pl.ids16.push_back(i);  // one LZ77 window (it starts at 0): positions fit a 16-bit slot
+    } else if (nch > 0) {
+      pl.ids32.push_back(i);
+    }
+    chunks += nch;
+    if (chunks > 0xffffffffull) return FLATE_HIP_E_TOO_LARGE;
+    slot += (flate_hip_deflate_bound((size_t)len) + 4 + 15) & ~15ull;
+  }
+  pl.chunk_base[n] = (uint32_t)chunks;
+  pl.slot_off[n] = slot;
+  pl.n_chunks = (uint32_t)chunks;
+  return FLATE_HIP_OK;
+}
+
+struct StageTimer {
+  flate_hip_ctx *c;
+  int stage;
+  StageTimer(flate_hip_ctx *ctx, int s) : c(ctx), stage(s) {
+    if (c->profiling) (void)hipEventRecord(c->ev[2 * stage], c->stream);
+  }
+  ~StageTimer() {
+    if (c->profiling) (void)hipEventRecord(c->ev[2 * stage + 1], c->stream);
+  }
+};
+
+int collect_timing(flate_hip_ctx *c, const bool used[FLATE_HIP_STAGE_COUNT]) {
+  for (int s = 0; s < FLATE_HIP_STAGE_COUNT; ++s) {
+    c->stage_ms[s] = 0.f;
+    if (c->profiling && used[s]) {
+      float ms = 0.f;
+      HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[2 * s], c->ev[2 * s + 1]));
+      c->stage_ms[s] = ms;
+    }
+  }
+  return FLATE_HIP_OK;
+}
+
+// Upload the index arrays and run the match finder over every LZ77 chunk.
+int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, const StagePlan &pl,
+             uint32_t flags) {
+  const uint32_t n = pl.n_streams;
+  int rc;
+  if ((rc = ensure(c, c->d_in_off, ((size_t)n + 1) * 8))) return rc;
+  if ((rc = ensure(c, c->d_chunk_base, ((size_t)n + 1) * 4))) return rc;
+  if ((rc = ensure(c, c->d_ids16, pl.ids16.size() * 4 + 4))) return rc;
+  if ((rc = ensure(c, c->d_ids32, pl.ids32.size() * 4 + 4))) return rc;
+  if ((rc = ensure(c, c->d_matches, (size_t)pl.n_chunks * kMatchCapPerChunk * sizeof(uint2) + 16)))
+    return rc;
+  if ((rc = ensure(c, c->d_nmatch, (size_t)pl.n_chunks * 4 + 4))) return rc;
+  if ((rc = ensure(c, c->d_ntok, (size_t)pl.n_chunks * 4 + 4))) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->d_in_off.p, in_off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice,
+                            c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_chunk_base.p, pl.chunk_base.data(), ((size_t)n + 1) * 4,
+                            hipMemcpyHostToDevice, c->stream));
+  if (!pl.ids16.empty())
+    HIP_TRY(c, hipMemcpyAsync(c->d_ids16.p, pl.ids16.data(), pl.ids16.size() * 4,
+                              hipMemcpyHostToDevice, c->stream));
+  if (!pl.ids32.empty())
+    HIP_TRY(c, hipMemcpyAsync(c->d_ids32.p, pl.ids32.data(), pl.ids32.size() * 4,
+                              hipMemcpyHostToDevice, c->stream));
+
+  LzParams P;
+  P.in = d_in;
+  P.in_off = (const uint64_t *)c->d_in_off.p;
+  P.chunk_base = (const uint32_t *)c->d_chunk_base.p;
+  P.stream_ids = nullptr;
+  P.scan_off = (const uint16_t *)c->scan_tab.p;
+  P.scan_len = c->scan_len;
+  P.matches = (uint2 *)c->d_matches.p;
+  P.chunk_nmatch = (uint32_t *)c->d_nmatch.p;
+  P.chunk_ntok = (uint32_t *)c->d_ntok.p;
+  P.compat_go = (flags & FLATE_HIP_COMPAT_GO) ? 1u : 0u;
+  {
+    StageTimer t(c, FLATE_HIP_STAGE_LZ77);
+    if (flags & FLATE_HIP_LZ_SERIAL) {
+      if (!pl.ids16.empty()) {
+        P.stream_ids = (const uint32_t *)c->d_ids16.p;
+        hipLaunchKernelGGL(lz77_serial_kernel, dim3((uint32_t)pl.ids16.size()), dim3(64), 0,
+                           c->stream, P);
+      }
+      if (!pl.ids32.empty()) {
+        P.stream_ids = (const uint32_t *)c->d_ids32.p;
+        hipLaunchKernelGGL(lz77_serial_kernel, dim3((uint32_t)pl.ids32.size()), dim3(64), 0,
+                           c->stream, P);
+      }
+    } else {
+      if (!pl.ids16.empty()) {
+        P.stream_ids = (const uint32_t *)c->d_ids16.p;
+        hipLaunchKernelGGL(lz77_wave_kernel<uint16_t>, dim3((uint32_t)pl.ids16.size()), dim3(64),
+                           0, c->stream, P);
+      }
+      if (!pl.ids32.empty()) {
+        P.stream_ids = (const uint32_t *)c->d_ids32.p;
+        hipLaunchKernelGGL(lz77_wave_kernel<uint32_t>, dim3((uint32_t)pl.ids32.size()), dim3(64),
+                           0, c->stream, P);
+      }
+    }
+  }
+  HIP_TRY(c, hipGetLastError());
+  return FLATE_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *flate_hip_strerror(int code) {
+  switch (code) {
+    case FLATE_HIP_OK: return "ok";
+    case FLATE_HIP_E_INVALID: return "invalid argument";
+    case FLATE_HIP_E_OUT_TOO_SMALL: return "output buffer too small";
+    case FLATE_HIP_E_HIP: return "HIP runtime error";
+    case FLATE_HIP_E_CORRUPT: return "flate: corrupt input";
+    case FLATE_HIP_E_NO_DEVICE: return "no usable HIP device (this engine has no CPU path)";
+    case FLATE_HIP_E_TOO_LARGE: return "stream too large";
+    case FLATE_HIP_E_UNEXPECTED_EOF: return "unexpected EOF";
+    default: return "unknown error";
+  }
+}
+
+const char *flate_hip_last_hip_error(const flate_hip_ctx *ctx) {
+  return ctx ? ctx->hip_err.c_str() : "";
+}
+
+const char *flate_hip_stage_name(int stage) {
+  switch (stage) {
+    case FLATE_HIP_STAGE_LZ77: return "lz77_match";
+    case FLATE_HIP_STAGE_HUFF_PACK: return "huff_pack";
+    case FLATE_HIP_STAGE_COMPACT: return "compact";
+    case FLATE_HIP_STAGE_INFLATE: return "inflate";
+    default: return "?";
+  }
+}
+
+int flate_hip_init(int device, flate_hip_ctx **out) {
+  if (!out) return FLATE_HIP_E_INVALID;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count)
+    return FLATE_HIP_E_NO_DEVICE;
+  flate_hip_ctx *c = new flate_hip_ctx();
+  c->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->own_stream) != hipSuccess) {
+    delete c;
+    return FLATE_HIP_E_NO_DEVICE;
+  }
+  c->stream = c->own_stream;
+  for (auto &e : c->ev)
+    if (hipEventCreate(&e) != hipSuccess) {
+      delete c;
+      return FLATE_HIP_E_HIP;
+    }
+  std::vector<uint16_t> tab = make_scan_table();
+  c->scan_len = (int)tab.size();
+  if (ensure(c, c->scan_tab, tab.size() * 2) != FLATE_HIP_OK ||
+      hipMemcpy(c->scan_tab.p, tab.data(), tab.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
+      ensure(c, c->d_status, 16) != FLATE_HIP_OK) {
+    flate_hip_destroy(c);
+    return FLATE_HIP_E_HIP;
+  }
+  *out = c;
+  return FLATE_HIP_OK;
+}
+
+void flate_hip_destroy(flate_hip_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+  for (DevBuf *b : {&c->scan_tab, &c->d_in, &c->d_out, &c->d_in_off, &c->d_chunk_base, &c->d_ids16,
+                    &c->d_ids32, &c->d_matches, &c->d_nmatch, &c->d_ntok, &c->d_slots,
+                    &c->d_slot_off, &c->d_out_len, &c->d_out_off, &c->d_status, &c->d_istatus,
+                    &c->d_ierr})
+    release(*b);
+  for (auto &e : c->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+int flate_hip_set_stream(flate_hip_ctx *c, void *hip_stream) {
+  if (!c) return FLATE_HIP_E_INVALID;
+  c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+  return FLATE_HIP_OK;
+}
+
+int flate_hip_set_profiling(flate_hip_ctx *c, int on) {
+  if (!c) return FLATE_HIP_E_INVALID;
+  c->profiling = on != 0;
+  return FLATE_HIP_OK;
+}
+
+int flate_hip_last_timing(flate_hip_ctx *c, float *ms, int n) {
+  if (!c || !ms) return FLATE_HIP_E_INVALID;
+  for (int i = 0; i < n && i < FLATE_HIP_STAGE_COUNT; ++i) ms[i] = c->stage_ms[i];
+  return FLATE_HIP_OK;
+}
+
+// Worst case of one stream: every window Huffman-coded with matches (< 15 bits per
+// byte), a <= 320-byte dynamic header per window, 5 bytes per stored block.
+size_t flate_hip_deflate_bound(size_t n) {
+  const size_t windows = n / kMaxStoreBlockSize + 1;
+  return n * 2 + windows * 320 + 16;
+}
+
+int flate_hip_deflate_fast_batch(flate_hip_ctx *c, const uint8_t *in, const uint64_t *in_off,
+                                 uint32_t n, uint8_t *out, uint64_t out_cap, uint64_t *out_off,
+                                 uint32_t flags) {
+  if (!c || !in_off || !out_off || (n && (!in || !out))) return FLATE_HIP_E_INVALID;
+  c->hip_err.clear();
+  if (n == 0) {
+    out_off[0] = 0;
+    return FLATE_HIP_OK;
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  StagePlan pl;
+  int rc = make_plan(in_off, n, pl);
+  if (rc) return rc;
+  const bool dev = (flags & FLATE_HIP_DEVICE_PTRS) != 0;
+  const uint64_t in_bytes = in_off[n];
+
+  const uint8_t *d_in = in;
+  uint8_t *d_out = out;
+  if (!dev) {
+    if ((rc = ensure(c, c->d_in, in_bytes + 16))) return rc;
+    if ((rc = ensure(c, c->d_out, out_cap + 16))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->d_in.p, in, in_bytes, hipMemcpyHostToDevice, c->stream));
+    d_in = (const uint8_t *)c->d_in.p;
+    d_out = (uint8_t *)c->d_out.p;
+  }
+  if ((rc = run_lz77(c, d_in, in_off, pl, flags))) return rc;
+
+  if ((rc = ensure(c, c->d_slots, pl.slot_off[n] + 64))) return rc;
+  if ((rc = ensure(c, c->d_slot_off, ((size_t)n + 1) * 8))) return rc;
+  if ((rc = ensure(c, c->d_out_len, (size_t)n * 8 + 8))) return rc;
+  if ((rc = ensure(c, c->d_out_off, ((size_t)n + 1) * 8))) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->d_slot_off.p, pl.slot_off.data(), ((size_t)n + 1) * 8,
+                            hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemsetAsync(c->d_status.p, 0, 4, c->stream));
+
+  HuffParams H;
+  H.in = d_in;
+  H.in_off = (const uint64_t *)c->d_in_off.p;
+  H.chunk_base = (const uint32_t *)c->d_chunk_base.p;
+  H.matches = (const uint2 *)c->d_matches.p;
+  H.chunk_nmatch = (const uint32_t *)c->d_nmatch.p;
+  H.chunk_ntok = (const uint32_t *)c->d_ntok.p;
+  H.slots = (uint8_t *)c->d_slots.p;
+  H.slot_off = (const uint64_t *)c->d_slot_off.p;
+  H.out_len = (uint64_t *)c->d_out_len.p;
+  H.n_streams = n;
+  H.compat_go = (flags & FLATE_HIP_COMPAT_GO) ? 1u : 0u;
+  {
+    StageTimer t(c, FLATE_HIP_STAGE_HUFF_PACK);
+    hipLaunchKernelGGL(huff_pack_kernel, dim3(n), dim3(64), 0, c->stream, H);
+  }
+  HIP_TRY(c, hipGetLastError());
+
+  CompactParams C;
+  C.slots = (const uint8_t *)c->d_slots.p;
+  C.slot_off = (const uint64_t *)c->d_slot_off.p;
+  C.out_len = (const uint64_t *)c->d_out_len.p;
+  C.out_off = (uint64_t *)c->d_out_off.p;
+  C.out = d_out;
+  C.out_cap = out_cap;
+  C.n_streams = n;
+  C.status = (int *)c->d_status.p;
+  {
+    StageTimer t(c, FLATE_HIP_STAGE_COMPACT);
+    hipLaunchKernelGGL(scan_sizes_kernel, dim3(1), dim3(1024), 0, c->stream, C);
+    hipLaunchKernelGGL(compact_kernel, dim3(n), dim3(256), 0, c->stream, C);
+  }
+  HIP_TRY(c, hipGetLastError());
+
+  int status = 0;
+  HIP_TRY(c, hipMemcpyAsync(out_off, c->d_out_off.p, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost,
+                            c->stream));
+  HIP_TRY(c, hipMemcpyAsync(&status, c->d_status.p, 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (status) return status;
+  if (!dev) {
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_out.p, out_off[n], hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  const bool used[FLATE_HIP_STAGE_COUNT] = {true, true, true, false};
+  return collect_timing(c, used);
+}
+
+int flate_hip_lz77_matches(flate_hip_ctx *c, const uint8_t *in, const uint64_t *in_off, uint32_t n,
+                           uint32_t flags, uint32_t *n_chunks, uint64_t *n_recs_cap,
+                           uint32_t *chunk_nmatch, uint64_t *chunk_rec_off, uint32_t *recs) {
+  if (!c || !in_off || !n_chunks || !n_recs_cap) return FLATE_HIP_E_INVALID;
+  c->hip_err.clear();
+  StagePlan pl;
+  int rc = make_plan(in_off, n, pl);
+  if (rc) return rc;
+  *n_chunks = pl.n_chunks;
+  *n_recs_cap = (uint64_t)pl.n_chunks * kMatchCapPerChunk;
+  if (!recs) return FLATE_HIP_OK;
+  if (!in || !chunk_nmatch || !chunk_rec_off) return FLATE_HIP_E_INVALID;
+  if (pl.n_chunks == 0) return FLATE_HIP_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const bool dev = (flags & FLATE_HIP_DEVICE_PTRS) != 0;
+  const uint8_t *d_in = in;
+  if (!dev) {
+    if ((rc = ensure(c, c->d_in, in_off[n] + 16))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->d_in.p, in, in_off[n], hipMemcpyHostToDevice, c->stream));
+    d_in = (const uint8_t *)c->d_in.p;
+  }
+  if ((rc = run_lz77(c, d_in, in_off, pl, flags))) return rc;
+  HIP_TRY(c, hipMemcpyAsync(chunk_nmatch, c->d_nmatch.p, (size_t)pl.n_chunks * 4,
+                            hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (uint32_t k = 0; k <= pl.n_chunks; ++k) chunk_rec_off[k] = (uint64_t)k * kMatchCapPerChunk;
+  const hipMemcpyKind kind = dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  HIP_TRY(c, hipMemcpyAsync(recs, c->d_matches.p, (size_t)pl.n_chunks * kMatchCapPerChunk * 8, kind,
+                            c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const bool used[FLATE_HIP_STAGE_COUNT] = {true, false, false, false};
+  return collect_timing(c, used);
+}
+
+int flate_hip_inflate_batch(flate_hip_ctx *c, const uint8_t *in, const uint64_t *in_off, uint32_t n,
+                            uint8_t *out, const uint64_t *out_off, uint64_t *out_len,
+                            int32_t *status, int64_t *err_off, uint32_t flags) {
+  (void)in; (void)in_off; (void)n; (void)out; (void)out_off; (void)out_len; (void)status;
+  (void)err_off; (void)flags;
+  if (!c) return FLATE_HIP_E_INVALID;
+  c->hip_err = "inflate kernel not built yet";
+  return FLATE_HIP_E_INVALID;
+}
+
+}  // extern "C"

@@ -1,0 +1,628 @@
+// huff_pack_kernels.hip -- per-stream entropy stage for gfx950 (wave64).
+//
+// Replaces, for a batch of streams, the block writer of the reference:
+//   Compressor::enc_speed / close      deflate.mbt:236-277,157-183 (block policy)
+//   HuffmanBitWriter::write_block_dynamic / write_block_huff / write_stored_header
+//                                       huffman-bit-writer.mbt:496-542,738-824,474-487
+//   index_tokens / generate_codegen / dynamic_size / write_dynamic_header / write_tokens
+//                                       huffman-bit-writer.mbt:550-593,241-330,335-360,421-471,596-731
+//   HuffmanEncoder::generate            huffman-code.mbt:295-343
+//
+// One wavefront per stream.  Everything that is a loop over tokens or symbols in the
+// reference is a wave-parallel pass here:
+//  * the token sequence is never materialised: each lane owns one input position of a
+//    64-byte tile and decides from the (sorted) match records whether it is a literal,
+//    the start of a match, or covered by one;
+//  * code lengths come from a level-parallel package-merge that yields the same counts
+//    as the lazy boundary algorithm of huffman-code.mbt:112-244 (ties between a leaf
+//    and a pair go to the pair, as `next_char_freq < next_pair_freq` at :187 dictates);
+//  * bits are placed by a wavefront prefix scan of the per-lane code lengths and OR-ed
+//    into an LDS ring that is drained to HBM with coalesced dword stores (the 48-bit
+//    accumulator and 248-byte buffer of huffman-bit-writer.mbt:170-199 describe the
+//    same LSB-first bit string).
+#include "flate_kernels.h"
+
+namespace flate {
+
+namespace {
+
+constexpr int kRing = 256;  // dwords in the LDS bit ring (a tile adds <= 96 dwords)
+constexpr int kHdrMax = 704;
+
+// codegen_order, huffman-bit-writer.mbt:83-85 (RFC 1951 3.2.7)
+__constant__ uint8_t kCodegenOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+struct Shared {
+  uint32_t lit_freq[288];
+  uint32_t off_freq[32];
+  uint32_t cg_freq[20];
+  uint32_t lit_cl[288];  // (len << 16) | bit-reversed code
+  uint32_t off_cl[32];
+  uint32_t cg_cl[20];
+  // code construction scratch
+  uint32_t key[288];    // sort keys, then sorted leaf frequencies
+  uint32_t sfreq[288];  // leaves ascending by (freq, symbol)
+  uint16_t ssym[288];
+  uint32_t lv[2][576];  // package-merge level lists (ping-pong)
+  uint32_t pairs[288];
+  uint16_t leaf_rank[16][288];
+  uint8_t slen[288];
+  uint32_t counts[17];
+  uint32_t first_code[17];
+  uint32_t len_base[17];
+  // header
+  uint8_t codegen[320];
+  uint32_t hdr_val[kHdrMax];
+  uint8_t hdr_nb[kHdrMax];
+  uint32_t hdr_n;
+  uint32_t ring[kRing];
+};
+
+FLATE_D uint32_t rdlane(uint32_t v, int lane) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
+}
+FLATE_D uint32_t wave_sum(uint32_t v) {
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+FLATE_D uint32_t wave_max(uint32_t v) {
+  for (int d = 32; d >= 1; d >>= 1) {
+    uint32_t o = __shfl_xor(v, d);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+FLATE_D uint32_t wave_incl_scan(uint32_t v, int lane) {
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t o = __shfl_up(v, d);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+// ---- bit sink ----------------------------------------------------------------------
+struct BitSink {
+  uint32_t *ring;    // LDS, zero outside the pending window
+  uint32_t *out32;   // global slot, 4-byte aligned
+  uint64_t bitpos;   // bits written so far
+  uint32_t flushed;  // dwords already drained to out32
+};
+
+// Every lane appends nb (<= 48) bits, in lane order.
+FLATE_D void sink_emit(BitSink &S, uint64_t bits, uint32_t nb, int lane) {
+  const uint32_t incl = wave_incl_scan(nb, lane);
+  const uint32_t total = rdlane(incl, 63);
+  if (nb) {
+    const uint64_t q = S.bitpos + (incl - nb);
+    const uint32_t w = (uint32_t)(q >> 5);
+    const uint32_t sh = (uint32_t)q & 31u;
+    const uint32_t d0 = (uint32_t)bits << sh;
+    const uint64_t rest = bits >> (32u - sh);  // sh == 0 -> bits >> 32
+    const uint32_t d1 = sh ? (uint32_t)rest : (uint32_t)(bits >> 32);
+    const uint32_t d2 = sh ? (uint32_t)(rest >> 32) : 0u;
+    if (d0) atomicOr(&S.ring[w & (kRing - 1)], d0);
+    if (d1) atomicOr(&S.ring[(w + 1) & (kRing - 1)], d1);
+    if (d2) atomicOr(&S.ring[(w + 2) & (kRing - 1)], d2);
+  }
+  S.bitpos += total;
+  __syncthreads();
+  while ((uint32_t)(S.bitpos >> 5) - S.flushed >= 64u) {
+    const uint32_t idx = S.flushed + (uint32_t)lane;
+    S.out32[idx] = S.ring[idx & (kRing - 1)];
+    S.ring[idx & (kRing - 1)] = 0;
+    S.flushed += 64;
+  }
+  __syncthreads();
+}
+
+// flush(): pad with zero bits to a byte boundary (huffman-bit-writer.mbt:139-158)
+FLATE_D void sink_pad_to_byte(BitSink &S) { S.bitpos = (S.bitpos + 7) & ~7ull; }
+
+// drain everything (stream end; bitpos is byte aligned)
+FLATE_D void sink_finish(BitSink &S, int lane) {
+  const uint32_t end = (uint32_t)((S.bitpos + 31) >> 5);
+  while (S.flushed < end) {
+    const uint32_t idx = S.flushed + (uint32_t)lane;
+    if (idx < end) {
+      S.out32[idx] = S.ring[idx & (kRing - 1)];
+      S.ring[idx & (kRing - 1)] = 0;
+    }
+    S.flushed += 64;
+  }
+  __syncthreads();
+}
+
+// ---- canonical length-limited Huffman code (huffman-code.mbt:295-343) ----------------
+// freq[0..nsym) -> cl[i] = (len << 16) | reversed code; len = 0 for absent symbols.
+FLATE_D void build_code(Shared &sh, const uint32_t *freq, int nsym, int max_bits, uint32_t *cl,
+                        int lane) {
+  // compact the symbols with non-zero frequency, in symbol order
+  int n = 0;
+  for (int base = 0; base < nsym; base += 64) {
+    const int i = base + lane;
+    const uint32_t f = i < nsym ? freq[i] : 0u;
+    const uint64_t m = __ballot(f != 0);
+    if (f != 0) {
+      const int r = n + __popcll(m & ((1ull << lane) - 1));
+      sh.key[r] = (f << 9) | (uint32_t)i;  // (freq, symbol) order, by_frequency :346
+    }
+    if (i < nsym) {
+      sh.slen[i] = 0;
+      cl[i] = 0;
+    }
+    n += __popcll(m);
+  }
+  __syncthreads();
+  if (n <= 2) {  // :326-336: lengths 1, codes 0/1 in symbol order
+    if (lane < n) cl[sh.key[lane] & 511u] = (1u << 16) | (uint32_t)lane;
+    __syncthreads();
+    return;
+  }
+
+  // rank sort (keys are distinct)
+  {
+    uint32_t mine[5];
+    int rank[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      const int j = lane + 64 * t;
+      mine[t] = j < n ? sh.key[j] : 0xffffffffu;
+      rank[t] = 0;
+    }
+    for (int k = 0; k < n; ++k) {
+      const uint32_t kk = sh.key[k];
+#pragma unroll
+      for (int t = 0; t < 5; ++t) rank[t] += kk < mine[t];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      const int j = lane + 64 * t;
+      if (j < n) {
+        sh.sfreq[rank[t]] = mine[t] >> 9;
+        sh.ssym[rank[t]] = (uint16_t)(mine[t] & 511u);
+      }
+    }
+    __syncthreads();
+  }
+
+  const int mb = max_bits < n - 1 ? max_bits : n - 1;  // :126-129
+
+  // level 1: the leaves themselves
+  for (int i = lane; i < n; i += 64) {
+    sh.lv[0][i] = sh.sfreq[i];
+    sh.leaf_rank[1][i] = (uint16_t)i;
+  }
+  __syncthreads();
+  int lp = n;  // length of the previous level's list
+  int cur = 0;
+  for (int lvl = 2; lvl <= mb; ++lvl) {
+    const uint32_t *prev = sh.lv[cur];
+    uint32_t *next = sh.lv[cur ^ 1];
+    const int np = lp >> 1;
+    for (int j = lane; j < np; j += 64) sh.pairs[j] = prev[2 * j] + prev[2 * j + 1];
+    __syncthreads();
+    // leaves: rank = i + #pairs with sum <= leaf (a pair wins a tie, :187)
+    for (int i = lane; i < n; i += 64) {
+      const uint32_t f = sh.sfreq[i];
+      int lo = 0, hi = np;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (sh.pairs[mid] <= f)
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      const int r = i + lo;
+      next[r] = f;
+      sh.leaf_rank[lvl][i] = (uint16_t)r;
+    }
+    // pairs: rank = j + #leaves with freq < sum
+    for (int j = lane; j < np; j += 64) {
+      const uint32_t ps = sh.pairs[j];
+      int lo = 0, hi = n;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (sh.sfreq[mid] < ps)
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      next[j + lo] = ps;
+    }
+    __syncthreads();
+    lp = n + np;
+    cur ^= 1;
+  }
+
+  // top-down: how many leaves sit in the needed prefix of each level (:168, :234-243)
+  {
+    uint32_t m = 2u * (uint32_t)n - 2u;
+    for (int lvl = mb; lvl >= 1; --lvl) {
+      uint32_t a = 0;
+      for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        a += __popcll(__ballot(i < n && (uint32_t)sh.leaf_rank[lvl][i] < m));
+      }
+      if (lane == 0) sh.counts[lvl] = a;
+      m = 2u * (m - a);
+    }
+    if (lane == 0) sh.counts[0] = 0;
+  }
+  __syncthreads();
+  // bit_count[b] = counts[mb-b+1] - counts[mb-b]; canonical first codes (:250-280)
+  if (lane == 0) {
+    uint32_t code = 0, cum = 0;
+    for (int b = 1; b <= mb; ++b) {
+      const uint32_t bc = sh.counts[mb - b + 1] - sh.counts[mb - b];
+      code <<= 1;
+      sh.first_code[b] = code;
+      code += bc;
+      cum += bc;
+      sh.len_base[b] = cum;  // symbols with length <= b, counted from the most frequent
+    }
+  }
+  __syncthreads();
+  // the n - len_base[b-1] .. most frequent leaves get the shortest codes
+  for (int j = lane; j < n; j += 64) {
+    const uint32_t from_top = (uint32_t)(n - 1 - j);  // 0 = most frequent
+    int b = 1;
+    while (b < mb && from_top >= sh.len_base[b]) ++b;
+    sh.slen[sh.ssym[j]] = (uint8_t)b;
+  }
+  __syncthreads();
+  // codes in symbol order within each length
+  uint32_t running[16];
+#pragma unroll
+  for (int b = 0; b < 16; ++b) running[b] = 0;
+  for (int base = 0; base < nsym; base += 64) {
+    const int i = base + lane;
+    const uint32_t L = i < nsym ? sh.slen[i] : 0u;
+    uint32_t code = 0;
+#pragma unroll
+    for (int b = 1; b < 16; ++b) {
+      const uint64_t m = __ballot(L == (uint32_t)b);
+      if (L == (uint32_t)b) code = sh.first_code[b] + running[b] + __popcll(m & ((1ull << lane) - 1));
+      running[b] += __popcll(m);
+    }
+    if (L) cl[i] = (L << 16) | (__brev(code) >> (32 - L));
+  }
+  __syncthreads();
+}
+
+// ---- tile walk over the implied token sequence ----------------------------------------
+struct TileTok {
+  bool is_lit;    // this lane's position is a literal
+  bool is_match;  // this lane's position starts a match
+  uint32_t byte;
+  uint32_t tok;
+};
+
+struct Walker {
+  const uint8_t *src;
+  const uint2 *recs;
+  uint32_t nm;
+  int n;
+  uint32_t mp;         // next match record
+  uint32_t cov_until;  // positions < cov_until are covered by an earlier match
+};
+
+FLATE_D TileTok walk_tile(Walker &w, int P0, int lane) {
+  TileTok t;
+  const int pos = P0 + lane;
+  uint2 rec = make_uint2(0xffffffffu, 0);
+  if (lane < 16 && w.mp + (uint32_t)lane < w.nm) rec = w.recs[w.mp + lane];
+  const uint64_t mine = __ballot(rec.x < (uint32_t)(P0 + 64));
+  const int cnt = __popcll(mine);
+  bool covered = (uint32_t)pos < w.cov_until;
+  uint32_t tok = 0;
+  for (int k = 0; k < cnt; ++k) {
+    const uint32_t pk = rdlane(rec.x, k), tk = rdlane(rec.y, k);
+    const uint32_t lk = ((tk >> kLengthShift) & 0xffu) + 3u;
+    if ((uint32_t)pos == pk)
+      tok = tk;
+    else if ((uint32_t)pos > pk && (uint32_t)pos < pk + lk)
+      covered = true;
+    if (k == cnt - 1) w.cov_until = pk + lk;
+  }
+  w.mp += (uint32_t)cnt;
+  const bool active = pos < w.n;
+  t.byte = active ? w.src[pos] : 0u;
+  t.is_match = active && tok != 0;
+  t.is_lit = active && !covered && tok == 0;
+  t.tok = tok;
+  return t;
+}
+
+// Emit the dynamic header (huffman-bit-writer.mbt:421-471) from hdr_val/hdr_nb.
+FLATE_D void emit_items(Shared &sh, BitSink &S, int lane) {
+  const int n = (int)sh.hdr_n;
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    const uint32_t nb = i < n ? sh.hdr_nb[i] : 0u;
+    const uint64_t v = i < n ? sh.hdr_val[i] : 0u;
+    sink_emit(S, v, nb, lane);
+  }
+}
+
+// stored block: header, pad, LEN, ~LEN, raw bytes (huffman-bit-writer.mbt:474-487,202-225)
+FLATE_D void emit_stored(BitSink &S, const uint8_t *src, int n, bool eof, int lane) {
+  sink_emit(S, eof ? 1u : 0u, lane == 0 ? 3u : 0u, lane);
+  sink_pad_to_byte(S);
+  const uint32_t lenw = (uint32_t)n | (((~(uint32_t)n) & 0xffffu) << 16);
+  sink_emit(S, lenw, lane == 0 ? 32u : 0u, lane);
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    sink_emit(S, i < n ? src[i] : 0u, i < n ? 8u : 0u, lane);
+  }
+}
+
+// generate_codegen (:241-330) + codegen code + dynamic_size (:335-360) + header items.
+// Returns size in bits (for the stored decision) and leaves the header in hdr_*.
+FLATE_D uint32_t make_header(Shared &sh, int num_literals, int num_offsets, int lane) {
+  if (lane < 20) sh.cg_freq[lane] = 0;
+  __syncthreads();
+  if (lane == 0) {
+    // run-length code the concatenated code lengths
+    const int total = num_literals + num_offsets;
+    int out = 0;
+    int i = 0;
+    while (i < total) {
+      const uint32_t v = i < num_literals ? (sh.lit_cl[i] >> 16) : (sh.off_cl[i - num_literals] >> 16);
+      int j = i + 1;
+      while (j < total) {
+        const uint32_t u = j < num_literals ? (sh.lit_cl[j] >> 16) : (sh.off_cl[j - num_literals] >> 16);
+        if (u != v) break;
+        ++j;
+      }
+      int count = j - i;
+      if (v != 0) {
+        sh.codegen[out++] = (uint8_t)v;
+        sh.cg_freq[v]++;
+        count--;
+        while (count >= 3) {
+          const int r = count < 6 ? count : 6;
+          sh.codegen[out++] = 16;
+          sh.codegen[out++] = (uint8_t)(r - 3);
+          sh.cg_freq[16]++;
+          count -= r;
+        }
+      } else {
+        while (count >= 11) {
+          const int r = count < 138 ? count : 138;
+          sh.codegen[out++] = 18;
+          sh.codegen[out++] = (uint8_t)(r - 11);
+          sh.cg_freq[18]++;
+          count -= r;
+        }
+        if (count >= 3) {
+          sh.codegen[out++] = 17;
+          sh.codegen[out++] = (uint8_t)(count - 3);
+          sh.cg_freq[17]++;
+          count = 0;
+        }
+      }
+      for (; count > 0; --count) {
+        sh.codegen[out++] = (uint8_t)v;
+        sh.cg_freq[v]++;
+      }
+      i = j;
+    }
+    sh.codegen[out] = 0xff;  // bad_code terminator (:329)
+  }
+  __syncthreads();
+  build_code(sh, sh.cg_freq, kCodegenCodeCount, 7, sh.cg_cl, lane);
+
+  uint32_t size = 0;
+  if (lane == 0) {
+    const uint8_t *order = kCodegenOrder;
+    int ncg = kCodegenCodeCount;
+    while (ncg > 4 && sh.cg_freq[order[ncg - 1]] == 0) ncg--;
+    uint32_t header = 3 + 5 + 5 + 4 + 3 * (uint32_t)ncg + sh.cg_freq[16] * 2 +
+                      sh.cg_freq[17] * 3 + sh.cg_freq[18] * 7;
+    for (int k = 0; k < kCodegenCodeCount; ++k) header += sh.cg_freq[k] * (sh.cg_cl[k] >> 16);
+    size = header;
+    int h = 0;
+    sh.hdr_val[h] = 4;  // BFINAL=0, BTYPE=10 (callers never pass eof, deflate.mbt:251,267,269)
+    sh.hdr_nb[h++] = 3;
+    sh.hdr_val[h] = (uint32_t)(num_literals - 257);
+    sh.hdr_nb[h++] = 5;
+    sh.hdr_val[h] = (uint32_t)(num_offsets - 1);
+    sh.hdr_nb[h++] = 5;
+    sh.hdr_val[h] = (uint32_t)(ncg - 4);
+    sh.hdr_nb[h++] = 4;
+    for (int k = 0; k < ncg; ++k) {
+      sh.hdr_val[h] = sh.cg_cl[order[k]] >> 16;
+      sh.hdr_nb[h++] = 3;
+    }
+    for (int k = 0;; ++k) {
+      const uint32_t cw = sh.codegen[k];
+      if (cw == 0xff) break;
+      const uint32_t c = sh.cg_cl[cw];
+      sh.hdr_val[h] = c & 0xffffu;
+      sh.hdr_nb[h++] = (uint8_t)(c >> 16);
+      if (cw >= 16) {
+        sh.hdr_val[h] = sh.codegen[++k];
+        sh.hdr_nb[h++] = cw == 16 ? 2 : (cw == 17 ? 3 : 7);
+      }
+    }
+    sh.hdr_n = (uint32_t)h;
+  }
+  size = rdlane(size, 0);
+  __syncthreads();
+  return size;
+}
+
+FLATE_D bool prefer_stored(uint32_t compat_go, int n, uint32_t size) {
+  // stored_size (:375-384): n in 1..65535 is always storable here.
+  const uint32_t ssize = ((uint32_t)n + 5u) * 8u;
+  if (compat_go) return ssize < size + (size >> 4);  // Go 1.23.1
+  return ssize < ((size + size) >> 4);               // huffman-bit-writer.mbt:527,780
+}
+
+// write_block_huff (:738-824): literal-only block over src[0..n)
+FLATE_D void block_huff(Shared &sh, BitSink &S, const HuffParams &P, const uint8_t *src, int n,
+                        int lane) {
+  for (int i = lane; i < 288; i += 64) sh.lit_freq[i] = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    if (i < n) atomicAdd(&sh.lit_freq[src[i]], 1u);
+  }
+  __syncthreads();
+  if (lane == 0) sh.lit_freq[kEndBlockMarker] = 1;
+  __syncthreads();
+  build_code(sh, sh.lit_freq, kMaxNumLit, 15, sh.lit_cl, lane);
+  // huff_offset (huffman-code.mbt:691-726): code 0 has length 1, nothing else
+  if (lane < 32) sh.off_cl[lane] = lane == 0 ? (1u << 16) : 0u;
+  __syncthreads();
+  uint32_t size = make_header(sh, kEndBlockMarker + 1, 1, lane);
+  uint32_t part = 0;
+  for (int i = lane; i < kMaxNumLit; i += 64) part += sh.lit_freq[i] * (sh.lit_cl[i] >> 16);
+  size += wave_sum(part) + 1u;  // + offset_freq[0] (=1) * 1 bit
+  if (prefer_stored(P.compat_go, n, size)) {
+    emit_stored(S, src, n, false, lane);
+    return;
+  }
+  emit_items(sh, S, lane);
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    uint32_t c = 0;
+    if (i < n) c = sh.lit_cl[src[i]];
+    sink_emit(S, c & 0xffffu, c >> 16, lane);
+  }
+  const uint32_t eob = sh.lit_cl[kEndBlockMarker];
+  sink_emit(S, eob & 0xffffu, lane == 0 ? (eob >> 16) : 0u, lane);
+}
+
+// write_block_dynamic (:496-542) over the implied token sequence of one LZ77 chunk
+FLATE_D void block_dynamic(Shared &sh, BitSink &S, const HuffParams &P, const uint8_t *src, int n,
+                           const uint2 *recs, uint32_t nm, int lane) {
+  for (int i = lane; i < 288; i += 64) sh.lit_freq[i] = 0;
+  if (lane < 32) sh.off_freq[lane] = 0;
+  __syncthreads();
+  // index_tokens (:550-593)
+  {
+    Walker w = {src, recs, nm, n, 0u, 0u};
+    for (int P0 = 0; P0 < n; P0 += 64) {
+      const TileTok t = walk_tile(w, P0, lane);
+      if (t.is_match) {
+        const CodeBits lc = length_code_of((t.tok >> kLengthShift) & 0xffu);
+        const CodeBits oc = offset_code_of(t.tok & ((1u << kLengthShift) - 1u));
+        atomicAdd(&sh.lit_freq[kLengthCodesStart + lc.code], 1u);
+        atomicAdd(&sh.off_freq[oc.code], 1u);
+      } else if (t.is_lit) {
+        atomicAdd(&sh.lit_freq[t.byte], 1u);
+      }
+    }
+    if (lane == 0) atomicAdd(&sh.lit_freq[kEndBlockMarker], 1u);  // tokens.push(EOB), :507
+  }
+  __syncthreads();
+  int num_literals, num_offsets;
+  {
+    uint32_t hi = 0;
+    for (int i = lane; i < kMaxNumLit; i += 64)
+      if (sh.lit_freq[i]) hi = (uint32_t)i + 1;
+    num_literals = (int)wave_max(hi);
+    uint32_t ho = (lane < kOffsetCodeCount && sh.off_freq[lane]) ? (uint32_t)lane + 1 : 0u;
+    num_offsets = (int)wave_max(ho);
+    if (num_offsets == 0) {  // :584-589
+      if (lane == 0) sh.off_freq[0] = 1;
+      num_offsets = 1;
+    }
+  }
+  __syncthreads();
+  build_code(sh, sh.lit_freq, kMaxNumLit, 15, sh.lit_cl, lane);
+  build_code(sh, sh.off_freq, kOffsetCodeCount, 15, sh.off_cl, lane);
+  uint32_t size = make_header(sh, num_literals, num_offsets, lane);
+  {
+    uint32_t part = 0;
+    for (int i = lane; i < kMaxNumLit; i += 64) part += sh.lit_freq[i] * (sh.lit_cl[i] >> 16);
+    if (lane < kOffsetCodeCount) part += sh.off_freq[lane] * (sh.off_cl[lane] >> 16);
+    size += wave_sum(part);  // extra bits are NOT counted (callers pass 0, :519-523)
+  }
+  if (prefer_stored(P.compat_go, n, size)) {
+    emit_stored(S, src, n, false, lane);
+    return;
+  }
+  emit_items(sh, S, lane);
+  // write_tokens (:596-731)
+  Walker w = {src, recs, nm, n, 0u, 0u};
+  for (int P0 = 0; P0 < n; P0 += 64) {
+    const TileTok t = walk_tile(w, P0, lane);
+    uint64_t bits = 0;
+    uint32_t nb = 0;
+    if (t.is_match) {
+      const CodeBits lc = length_code_of((t.tok >> kLengthShift) & 0xffu);
+      const CodeBits oc = offset_code_of(t.tok & ((1u << kLengthShift) - 1u));
+      const uint32_t c1 = sh.lit_cl[kLengthCodesStart + lc.code];
+      const uint32_t c2 = sh.off_cl[oc.code];
+      bits = c1 & 0xffffu;
+      nb = c1 >> 16;
+      bits |= (uint64_t)lc.extra << nb;
+      nb += lc.nextra;
+      bits |= (uint64_t)(c2 & 0xffffu) << nb;
+      nb += c2 >> 16;
+      bits |= (uint64_t)oc.extra << nb;
+      nb += oc.nextra;
+    } else if (t.is_lit) {
+      const uint32_t c = sh.lit_cl[t.byte];
+      bits = c & 0xffffu;
+      nb = c >> 16;
+    }
+    sink_emit(S, bits, nb, lane);
+  }
+  const uint32_t eob = sh.lit_cl[kEndBlockMarker];
+  sink_emit(S, eob & 0xffffu, lane == 0 ? (eob >> 16) : 0u, lane);
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(64) void huff_pack_kernel(HuffParams P) {
+  __shared__ Shared sh;
+  const int lane = threadIdx.x;
+  const uint32_t sid = blockIdx.x;
+  if (sid >= P.n_streams) return;
+
+  const uint64_t a = P.in_off[sid];
+  const uint64_t L = P.in_off[sid + 1] - a;
+  const uint8_t *stream = P.in + a;
+  const uint32_t chunk0 = P.chunk_base[sid];
+
+  for (int i = lane; i < kRing; i += 64) sh.ring[i] = 0;
+  __syncthreads();
+  BitSink S;
+  S.ring = sh.ring;
+  S.out32 = reinterpret_cast<uint32_t *>(P.slots + P.slot_off[sid]);
+  S.bitpos = 0;
+  S.flushed = 0;
+
+  const uint64_t full = L / (uint64_t)kMaxStoreBlockSize;
+  const int r = (int)(L % (uint64_t)kMaxStoreBlockSize);
+  const uint64_t nblocks = full + (r > 0 ? 1 : 0);
+  for (uint64_t b = 0; b < nblocks; ++b) {
+    const uint8_t *src = stream + b * (uint64_t)kMaxStoreBlockSize;
+    const int n = b < full ? kMaxStoreBlockSize : r;
+    if (n < kSmallLzMin) {  // only the tail can be this short (deflate.mbt:243-256)
+      if (n <= 16)
+        emit_stored(S, src, n, false, lane);
+      else
+        block_huff(sh, S, P, src, n, lane);
+      continue;
+    }
+    const uint32_t chunk = chunk0 + (uint32_t)b;
+    const uint32_t ntok = P.chunk_ntok[chunk];
+    if (ntok > (uint32_t)(n - (n >> 4))) {  // deflate.mbt:266
+      block_huff(sh, S, P, src, n, lane);
+    } else {
+      block_dynamic(sh, S, P, src, n, P.matches + (uint64_t)chunk * kMatchCapPerChunk,
+                    P.chunk_nmatch[chunk], lane);
+    }
+  }
+  // Compressor::close: empty stored block with BFINAL, then flush (deflate.mbt:171-176)
+  emit_stored(S, stream, 0, true, lane);
+  sink_finish(S, lane);
+  if (lane == 0) P.out_len[sid] = S.bitpos >> 3;
+}
+
+}  // namespace flate

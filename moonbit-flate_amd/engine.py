@@ -1,0 +1,188 @@
+"""Host-side handle of the MI355X batch DEFLATE engine (thin wrapper over the C ABI).
+
+The C ABI (include/flate_hip.h) is the product boundary; this module only marshals
+numpy / torch buffers into it.  PyTorch is used for device memory and streams only.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+
+DEVICE_PTRS = 0x1
+COMPAT_GO = 0x2
+LZ_SERIAL = 0x4
+
+SYNTH_RAMP, SYNTH_TEXT, SYNTH_RAND, SYNTH_ZERO = 0, 1, 2, 3
+SYNTH_KINDS = {"ramp": SYNTH_RAMP, "text": SYNTH_TEXT, "rand": SYNTH_RAND, "zero": SYNTH_ZERO}
+SEED_TEXT = 0x5EED0001
+SEED_RAND = 0x5EED0002
+
+STAGES = ("lz77_match", "huff_pack", "compact", "inflate")
+
+MAX_STORE_BLOCK_SIZE = 65535
+MATCH_CAP_PER_CHUNK = 16384
+
+
+class FlateError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("flate_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def deflate_bound(n):
+    return int(_lib.load().flate_hip_deflate_bound(int(n)))
+
+
+def synth(kind, n_streams, stream_len, seed=None, first_stream=0, nthreads=None):
+    """Synthetic benchmark input: n_streams streams of stream_len bytes, back to back."""
+    k = SYNTH_KINDS[kind] if isinstance(kind, str) else int(kind)
+    if seed is None:
+        seed = SEED_RAND if k == SYNTH_RAND else SEED_TEXT
+    if nthreads is None:
+        nthreads = min(16, os.cpu_count() or 1)
+    out = np.empty(int(n_streams) * int(stream_len), dtype=np.uint8)
+    rc = _lib.load().flate_hip_synth_fill(k, seed, first_stream, n_streams, stream_len,
+                                          out.ctypes.data, nthreads)
+    if rc != 0:
+        raise FlateError(rc, "synth_fill")
+    return out
+
+
+def uniform_offsets(n_streams, stream_len):
+    return (np.arange(n_streams + 1, dtype=np.uint64) * np.uint64(stream_len))
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+class FlateEngine:
+    """One engine = one flate_hip_ctx = one GPU + one HIP stream."""
+
+    def __init__(self, device=0):
+        self._L = _lib.load()
+        self._ctx = C.c_void_p()
+        rc = self._L.flate_hip_init(int(device), C.byref(self._ctx))
+        if rc != 0:
+            raise FlateError(rc, self._L.flate_hip_strerror(rc).decode())
+        self.device = int(device)
+
+    def close(self):
+        if self._ctx:
+            self._L.flate_hip_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = self._L.flate_hip_strerror(rc).decode()
+            extra = self._L.flate_hip_last_hip_error(self._ctx).decode()
+            raise FlateError(rc, msg + (" [" + extra + "]" if extra else ""))
+
+    def use_stream(self, hip_stream_ptr):
+        """Launch on the given hipStream_t (int address), e.g. torch.cuda.current_stream().cuda_stream."""
+        self._check(self._L.flate_hip_set_stream(self._ctx, C.c_void_p(hip_stream_ptr or None)))
+
+    def set_profiling(self, on=True):
+        self._check(self._L.flate_hip_set_profiling(self._ctx, 1 if on else 0))
+
+    def last_timing(self):
+        ms = (C.c_float * len(STAGES))()
+        self._check(self._L.flate_hip_last_timing(self._ctx, ms, len(STAGES)))
+        return {STAGES[i]: float(ms[i]) for i in range(len(STAGES))}
+
+    @staticmethod
+    def _flags(compat_go, lz_serial, device):
+        return (COMPAT_GO if compat_go else 0) | (LZ_SERIAL if lz_serial else 0) | \
+               (DEVICE_PTRS if device else 0)
+
+    def deflate_batch(self, data, in_off, out=None, out_cap=None, compat_go=False, lz_serial=False):
+        """Compress independent streams: stream i = data[in_off[i]:in_off[i+1]] with fresh-Writer
+        semantics.  data: numpy uint8 array (host) or torch uint8 CUDA tensor (device).
+        Returns (out, out_off): out has the same kind as data, out_off is numpy uint64[n+1]."""
+        in_off = np.ascontiguousarray(in_off, dtype=np.uint64)
+        n = in_off.size - 1
+        out_off = np.zeros(n + 1, dtype=np.uint64)
+        device = _is_torch(data)
+        if out_cap is None and out is None:
+            lens = in_off[1:] - in_off[:-1]
+            out_cap = sum(deflate_bound(int(l)) * int(c)
+                          for l, c in zip(*np.unique(lens, return_counts=True)))
+        if device:
+            import torch
+            assert data.dtype == torch.uint8 and data.is_cuda and data.is_contiguous()
+            if out is None:
+                out = torch.empty(max(int(out_cap), 16), dtype=torch.uint8, device=data.device)
+            cap = out.numel()
+            in_ptr, out_ptr = data.data_ptr(), out.data_ptr()
+        else:
+            data = np.ascontiguousarray(data, dtype=np.uint8)
+            if out is None:
+                out = np.empty(max(int(out_cap), 16), dtype=np.uint8)
+            cap = out.size
+            in_ptr, out_ptr = data.ctypes.data, out.ctypes.data
+        rc = self._L.flate_hip_deflate_fast_batch(self._ctx, in_ptr, in_off.ctypes.data, n, out_ptr,
+                                                  cap, out_off.ctypes.data,
+                                                  self._flags(compat_go, lz_serial, device))
+        self._check(rc)
+        return out, out_off
+
+    def lz77_matches(self, data, in_off, compat_go=False, lz_serial=False):
+        """Match finder only.  Returns a list over LZ77 chunks (stream order) of
+        (pos uint32[], tok uint32[]) and the per-stream chunk counts."""
+        in_off = np.ascontiguousarray(in_off, dtype=np.uint64)
+        n = in_off.size - 1
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        n_chunks, cap = C.c_uint32(0), C.c_uint64(0)
+        flags = self._flags(compat_go, lz_serial, False)
+        self._check(self._L.flate_hip_lz77_matches(self._ctx, data.ctypes.data, in_off.ctypes.data, n,
+                                                   flags, C.byref(n_chunks), C.byref(cap),
+                                                   None, None, None))
+        nc = n_chunks.value
+        nmatch = np.zeros(max(nc, 1), dtype=np.uint32)
+        rec_off = np.zeros(nc + 1, dtype=np.uint64)
+        recs = np.zeros((max(cap.value, 1), 2), dtype=np.uint32)
+        self._check(self._L.flate_hip_lz77_matches(self._ctx, data.ctypes.data, in_off.ctypes.data, n,
+                                                   flags, C.byref(n_chunks), C.byref(cap),
+                                                   nmatch.ctypes.data, rec_off.ctypes.data,
+                                                   recs.ctypes.data))
+        out = []
+        for c in range(nc):
+            r = recs[int(rec_off[c]):int(rec_off[c]) + int(nmatch[c])]
+            out.append((r[:, 0].copy(), r[:, 1].copy()))
+        return out
+
+
+def lz_chunks(stream_len):
+    """(start, length) of the LZ77 chunks of one stream (Compressor::enc_speed policy)."""
+    full, r = divmod(int(stream_len), MAX_STORE_BLOCK_SIZE)
+    ch = [(i * MAX_STORE_BLOCK_SIZE, MAX_STORE_BLOCK_SIZE) for i in range(full)]
+    if r >= 128:
+        ch.append((full * MAX_STORE_BLOCK_SIZE, r))
+    return ch
+
+
+def tokens_from_matches(chunk_bytes, pos, tok):
+    """Expand match records into the reference's token array (token.mbt:69,76)."""
+    src = np.frombuffer(bytes(chunk_bytes), dtype=np.uint8) if not isinstance(chunk_bytes, np.ndarray) \
+        else chunk_bytes
+    n = src.size
+    pos = pos.astype(np.int64)
+    lens = ((tok >> 22) & 0xFF).astype(np.int64) + 3
+    covered = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(covered, pos, 1)
+    np.add.at(covered, np.minimum(pos + lens, n), -1)
+    inside = np.cumsum(covered[:n]) > 0
+    is_start = np.zeros(n, dtype=bool)
+    is_start[pos] = True
+    keep = (~inside) | is_start
+    vals = src.astype(np.uint32)
+    vals[pos] = tok
+    return vals[keep]

@@ -1,0 +1,152 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI,
+must reproduce the oracle (CPU restatement of the reference) bit for bit."""
+import numpy as np
+import pytest
+
+from util import flate, make_streams, oracle_tokens_per_chunk, raw_inflate
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    flate.build()
+    e = flate.FlateEngine(0)
+    yield e
+    e.close()
+
+
+SINGLE_WINDOW = [
+    ("text", 65536), ("text", 65535), ("text", 40000), ("ramp", 65536), ("zero", 65536),
+    ("rand", 65536), ("low", 65536), ("period", 65536), ("runs", 65536), ("text", 128),
+    ("text", 129), ("text", 143), ("text", 1000), ("runs", 300), ("zero", 200), ("low", 5000),
+    ("period", 33000), ("rand", 128), ("ramp", 65534),
+]
+
+MULTI_WINDOW = [
+    ("text", 65537 + 200), ("text", 131072), ("ramp", 131072), ("period", 262144),
+    ("runs", 200000), ("zero", 140000), ("low", 131070), ("rand", 70000), ("text", 196605),
+    ("text", 65535 * 2 + 127), ("text", 65535 * 2 + 128),
+]
+
+
+def _check_tokens(eng, oracle, specs, lz_serial, compat_go=False):
+    data, off = make_streams(specs)
+    chunks = eng.lz77_matches(data, off, lz_serial=lz_serial, compat_go=compat_go)
+    k = 0
+    for i, (kind, n) in enumerate(specs):
+        sb = data[int(off[i]):int(off[i + 1])]
+        want = oracle_tokens_per_chunk(oracle, sb, compat=1 if compat_go else 0)
+        for (start, cn), w in zip(flate.lz_chunks(n), want):
+            pos, tok = chunks[k]
+            got = flate.tokens_from_matches(sb[start:start + cn], pos, tok)
+            assert got.size == w.size, (kind, n, start, got.size, w.size)
+            bad = np.nonzero(got != w)[0]
+            assert bad.size == 0, (kind, n, start, int(bad[0]), got[bad[0]], w[bad[0]])
+            k += 1
+    assert k == len(chunks)
+
+
+@pytest.mark.parametrize("lz_serial", [True, False], ids=["serial", "wave"])
+def test_tokens_single_window(eng, oracle, lz_serial):
+    _check_tokens(eng, oracle, SINGLE_WINDOW, lz_serial)
+
+
+@pytest.mark.parametrize("lz_serial", [True, False], ids=["serial", "wave"])
+def test_tokens_multi_window(eng, oracle, lz_serial):
+    _check_tokens(eng, oracle, MULTI_WINDOW, lz_serial)
+
+
+@pytest.mark.parametrize("lz_serial", [True, False], ids=["serial", "wave"])
+def test_tokens_multi_window_go_compat(eng, oracle, lz_serial):
+    _check_tokens(eng, oracle, MULTI_WINDOW, lz_serial, compat_go=True)
+
+
+EDGE_SIZES = [0, 1, 2, 15, 16, 17, 18, 100, 127, 128, 129, 255, 4096, 65534, 65535, 65536, 65537,
+              65535 + 16, 65535 + 17, 65535 + 127, 65535 + 128, 131070, 131071, 131072]
+
+
+def _check_streams(eng, oracle, specs, compat_go=False, device=False):
+    data, off = make_streams(specs)
+    if device:
+        import torch
+        d = torch.from_numpy(data).cuda()
+        out, out_off = eng.deflate_batch(d, off, compat_go=compat_go)
+        out = out.cpu().numpy()
+    else:
+        out, out_off = eng.deflate_batch(data, off, compat_go=compat_go)
+    for i, (kind, n) in enumerate(specs):
+        sb = data[int(off[i]):int(off[i + 1])] if n else np.zeros(0, np.uint8)
+        want = oracle.deflate(sb, compat=1 if compat_go else 0)
+        got = bytes(out[int(out_off[i]):int(out_off[i + 1])])
+        if got != want:
+            first = next((j for j in range(min(len(got), len(want))) if got[j] != want[j]), None)
+            raise AssertionError("stream %d (%s,%d): len got %d want %d first diff at %s" %
+                                 (i, kind, n, len(got), len(want), first))
+        assert raw_inflate(got) == bytes(sb)
+
+
+def test_streams_edge_sizes(eng, oracle):
+    _check_streams(eng, oracle, [("text", n) for n in EDGE_SIZES])
+    _check_streams(eng, oracle, [("ramp", n) for n in EDGE_SIZES])
+
+
+def test_streams_data_kinds(eng, oracle):
+    _check_streams(eng, oracle, SINGLE_WINDOW + MULTI_WINDOW)
+
+
+def test_streams_device_pointers(eng, oracle):
+    _check_streams(eng, oracle, SINGLE_WINDOW[:8] + MULTI_WINDOW[:3], device=True)
+
+
+def test_streams_go_compat(eng, oracle):
+    _check_streams(eng, oracle, SINGLE_WINDOW + MULTI_WINDOW, compat_go=True)
+
+
+def test_best_speed_matrix(eng, oracle):
+    # deflate-fast_test.mbt:14-100: the 96 streams of TestBestSpeed (write sizes only change
+    # how the window is staged, not the bytes), deduplicated by total content.
+    abc = (np.arange(131072) & 127).astype(np.uint8)
+    cases = [[0], [1], [1, 256], [1, 65536], [14], [15], [16], [16, 256], [16, 65536], [127],
+             [128], [128, 256], [128, 65536], [129], [65536, 256], [65536, 65536]]
+    streams = []
+    for tc in cases:
+        for first in [1, 65534, 65535, 65536, 65537, 131072]:
+            streams.append(np.concatenate([abc[:k] for k in [first] + tc]))
+    lens = np.array([s.size for s in streams], dtype=np.uint64)
+    off = np.zeros(len(streams) + 1, np.uint64)
+    np.cumsum(lens, out=off[1:])
+    data = np.concatenate(streams)
+    out, out_off = eng.deflate_batch(data, off)
+    for i, s in enumerate(streams):
+        got = bytes(out[int(out_off[i]):int(out_off[i + 1])])
+        assert got == oracle.deflate(s), i
+        assert raw_inflate(got) == bytes(s)
+
+
+def test_fuzz_random_lengths(eng, oracle):
+    rng = np.random.default_rng(99)
+    kinds = ["text", "low", "period", "runs", "rand", "zero", "ramp"]
+    specs = [(kinds[int(rng.integers(0, len(kinds)))], int(rng.integers(0, 150000)))
+             for _ in range(60)]
+    _check_streams(eng, oracle, specs)
+
+
+def test_out_too_small_is_reported(eng):
+    data, off = make_streams([("rand", 65536)] * 4)
+    with pytest.raises(flate.FlateError) as ei:
+        eng.deflate_batch(data, off, out_cap=1000)
+    assert ei.value.code == -2
+
+
+def test_batch_1k_streams_full_size(eng, oracle):
+    # 1024 x 64 KiB of S-text, byte-for-byte against the oracle (threads)
+    n = 1024
+    data = flate.synth("text", n, 65536)
+    off = flate.uniform_offsets(n, 65536)
+    out, out_off = eng.deflate_batch(data, off)
+    o_out, o_off, o_len = oracle.deflate_batch(data, off, nthreads=8)
+    for i in range(n):
+        a = out[int(out_off[i]):int(out_off[i + 1])]
+        b = o_out[int(o_off[i]):int(o_off[i]) + int(o_len[i])]
+        assert a.size == b.size and np.array_equal(a, b), i
