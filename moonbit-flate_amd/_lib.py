@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libflate_hip.so")
+# FLATE_HIP_LIB: developer override to A/B an experimental build of the same library
+LIB_PATH = os.environ.get("FLATE_HIP_LIB") or os.path.join(HERE, "lib", "libflate_hip.so")
 
 # every symbol include/flate_hip.h declares
 EXPORTS = [

@@ -16,7 +16,10 @@
 
 namespace flate {
 
-constexpr int kTableBits = 14;                  // deflate-fast.mbt:12
+#ifndef FLATE_EXPERIMENT_TABLE_BITS
+#define FLATE_EXPERIMENT_TABLE_BITS 14
+#endif
+constexpr int kTableBits = FLATE_EXPERIMENT_TABLE_BITS;  // deflate-fast.mbt:12 (14)
 constexpr int kTableSize = 1 << kTableBits;     // :15
 constexpr int kTableShift = 32 - kTableBits;    // :21
 constexpr int kMaxMatchOffset = 1 << 15;        // :40

@@ -154,7 +154,65 @@ __global__ __launch_bounds__(64) void lz77_serial_kernel(LzParams P) {
 
 // ---------------------------------------------------------------------------------
 // wave kernel
+//
+// Parser state (wave-uniform): POST(s) -- the previous event was a match ending at s
+// (chunk start is POST(-1)): re-insert s-1, probe s, then scan from s+1 with the skip
+// schedule restarted (:246-265, :178-202) -- or SPARSE(scan_base, e_idx): a scan that
+// has already run e_idx probes without success.
+//
+// POST is served by a DENSE batch: lane L owns position s-1+L.  Every lane loads its
+// 16 input bytes, hashes, reads its slot, checks its candidate and measures the match
+// (up to 16 bytes) -- one table gather and one input gather for 64 positions.  A
+// register-only event loop then walks the probe schedule: first lane with a valid
+// candidate = match, jump to its end, repeat inside the same batch (about six matches
+// per batch on text).  Lanes that share a table slot with another lane of the batch
+// (DUP, found by an LDS write/read-back) are judged exactly against the positions
+// already inserted by this batch.  Inserts are committed to LDS at the end of the batch.
+//
+// SPARSE is served by one probe event per lane (strides grow with the skip counter).
+// tests/host_model/lz77_wave_model.cpp is the lane-accurate CPU model of this kernel.
 // ---------------------------------------------------------------------------------
+constexpr int kDenseKeep = 46;  // keep using a dense batch while the next s-1 lane <= this
+
+FLATE_D uint64_t lanes_below(int l) { return l >= 64 ? ~0ull : ((1ull << l) - 1ull); }
+FLATE_D uint64_t lanes_upto(int l) { return l >= 63 ? ~0ull : ((1ull << (l + 1)) - 1ull); }
+FLATE_D int ffs64(uint64_t m) { return m ? __builtin_ctzll(m) : 64; }
+
+FLATE_D uint4 ld128(const uint8_t *p) {
+  uint4 v;
+  __builtin_memcpy(&v, p, 16);  // one unaligned global_load_dwordx4
+  return v;
+}
+
+// common prefix (bytes, 0..16) of two 16-byte strings
+FLATE_D int prefix16(uint4 a, uint4 b) {
+  const uint64_t lo = (uint64_t)(a.x ^ b.x) | ((uint64_t)(a.y ^ b.y) << 32);
+  const uint64_t hi = (uint64_t)(a.z ^ b.z) | ((uint64_t)(a.w ^ b.w) << 32);
+  if (lo) return __builtin_ctzll(lo) >> 3;
+  if (hi) return 8 + (__builtin_ctzll(hi) >> 3);
+  return 16;
+}
+
+// Total match length at chunk position pf against absolute position cand, `have` bytes
+// already known equal (match_len, deflate-fast.mbt:286-342), 64 lanes x 4 bytes.
+FLATE_D int extend_match(const uint8_t *src, const uint8_t *stream, uint32_t W, int n, int pf,
+                         uint32_t cand, int have, uint32_t compat_go, int lane) {
+  if (!compat_go && cand + 4 < W) return 4;  // MoonBit: prev window is empty
+  int limit = n - pf;
+  if (limit > 258) limit = 258;
+  const int o = have + 4 * lane;
+  uint32_t x = 0;
+  if (o < limit) {
+    const int r = limit - o;
+    const uint8_t *pa = src + pf + o, *pb = stream + cand + o;
+    x = r >= 4 ? (ld32(pa) ^ ld32(pb)) : (ld_partial(pa, r) ^ ld_partial(pb, r));
+  }
+  const uint64_t mm = __ballot(x != 0);
+  if (!mm) return limit;
+  const int k = __builtin_ctzll(mm);
+  return have + 4 * k + (__builtin_ctz(rdlane(x, k)) >> 3);
+}
+
 template <typename E>
 __global__ __launch_bounds__(64) void lz77_wave_kernel(LzParams P) {
   __shared__ E table[kTableSize];
@@ -167,155 +225,245 @@ __global__ __launch_bounds__(64) void lz77_wave_kernel(LzParams P) {
   }
   __syncthreads();
   volatile E *vtable = table;
+  constexpr uint32_t kEMask = sizeof(E) == 2 ? 0xffffu : 0xffffffffu;
 
   const ChunkGeom g = stream_geom(P, sid);
   const uint16_t *scan_tab = P.scan_off;
 
   for (uint32_t c = 0; c < g.nchunks; ++c) {
     const uint32_t W = c * (uint32_t)kMaxStoreBlockSize;
-    const uint64_t rem = g.len - W;
-    const int n = rem < (uint64_t)kMaxStoreBlockSize ? (int)rem : kMaxStoreBlockSize;
+    const uint64_t rem_len = g.len - W;
+    const int n = rem_len < (uint64_t)kMaxStoreBlockSize ? (int)rem_len : kMaxStoreBlockSize;
     const uint8_t *src = g.stream + W;
     uint2 *mout = P.matches + g.mbase + (uint64_t)c * kMatchCapPerChunk;
     uint32_t nm = 0, sumlen = 0;
     const int s_limit = n - kInputMargin;
 
-    // Wave-uniform parser state.  post: the previous event was a match ending at s
-    // (s < s_limit): lane 0 re-inserts s-1, lane 1 probes s, lanes 2.. run the scan
-    // that restarts at s+1 (:246-265, then :178-202).  Otherwise lanes continue the
-    // scan that started at scan_base with probe index e_idx.
-    bool post = false;
-    int s = 0, scan_base = 0, e_idx = 0;
+    int s = -1;
+    bool sparse = false;
+    int scan_base = 0, e_idx = 0;
+    bool done = false;
 
-    for (;;) {
-      // ---- lane -> probe event -------------------------------------------------
-      int p, step, e;
-      bool probe = true;
-      if (post) {
-        e = lane - 2;
-        if (lane < 2) {
-          p = s - 1 + lane;
-          step = 0;
-          probe = lane == 1;
-        } else {
-          p = s + 1 + scan_off_small(e, &step);
+    while (!done) {
+      if (!sparse) {
+        // =============================== dense batch ===============================
+        const int B = s - 1;
+        const int q = B + lane;
+        const bool e1 = q >= 0 && q + 1 <= s_limit;  // may be inserted / probed with step 1
+        const bool e2 = q >= 0 && q + 2 <= s_limit;  // may be probed with step 2
+        const uint64_t E1 = __ballot(e1), E2 = __ballot(e2);
+        const uint32_t A1 = W + (uint32_t)q + 1;
+        uint4 own = make_uint4(0, 0, 0, 0);
+        uint32_t h = 0, old = 0;
+        if (e1) {
+          own = ld128(src + q);
+          h = hash4(own.x);
+          old = vtable[h];
+        }
+        const bool inr = e1 && old != 0 && (A1 - old) <= (uint32_t)kMaxMatchOffset;
+        uint4 cb = own;
+        if (inr) cb = ld128(g.stream + (old - 1));
+        // duplicate-slot detection: speculative insert of all 64 positions + read-back
+        if (e1) vtable[h] = (E)A1;
+        const uint32_t rb = e1 ? (uint32_t)vtable[h] : (A1 & kEMask);
+        const bool loser = rb != (A1 & kEMask);
+        const uint64_t LM = __ballot(loser);
+        uint64_t DUP = LM;
+        if (LM) {
+          const int wl = (int)((rb - (W + (uint32_t)B + 1u)) & kEMask);  // lane that owns the slot
+          uint64_t m = LM;
+          while (m) {
+            const int w = (int)rdlane((uint32_t)wl, __builtin_ctzll(m));
+            DUP |= 1ull << w;
+            m &= ~__ballot(loser && wl == w);
+          }
+        }
+        const int mlen = inr ? prefix16(own, cb) : 0;
+        const uint64_t OK = __ballot(mlen >= 4);
+
+        uint64_t INS = 0;
+        int a = 0;
+        for (;;) {  // events inside this batch
+          const uint64_t a_ins = E1 & (1ull << a);
+          const int b = a + 2;
+          const uint64_t full = 0x55555555ffffffffull << b;  // scan probe lanes (steps 1 then 2)
+          const uint64_t scanR = ((0x00000000ffffffffull << b) & E1) | ((0x5555555500000000ull << b) & E2);
+          const uint64_t R = (E1 & (2ull << a)) | scanR;
+          const bool scan_ended = scanR != full;
+
+          uint64_t T = 0, rem = R;
+          int f = 64, have = 0;
+          uint32_t cand = 0;
+          for (;;) {
+            const int fv = ffs64(OK & rem & ~DUP), fd = ffs64(DUP & rem);
+            if (fv < fd) {
+              f = fv;
+              cand = rdlane(old, fv) - 1;
+              have = (int)rdlane((uint32_t)mlen, fv);
+              T |= rem & lanes_upto(fv);
+              break;
+            }
+            if (fd == 64) {
+              T |= rem;
+              break;
+            }
+            // lane fd shares its slot with other lanes of this batch: judge it against the
+            // latest position this batch has already inserted into that slot
+            T |= rem & lanes_below(fd);
+            const uint32_t hfd = rdlane(h, fd);
+            const uint64_t G = __ballot(e1 && h == hfd) & (INS | T | a_ins) & lanes_below(fd);
+            bool v;
+            uint32_t cnd;
+            int ml;
+            if (G) {
+              const int i = 63 - __builtin_clzll(G);
+              v = rdlane(own.x, i) == rdlane(own.x, fd);
+              cnd = W + (uint32_t)(B + i);
+              const uint4 oi = make_uint4(rdlane(own.x, i), rdlane(own.y, i), rdlane(own.z, i),
+                                          rdlane(own.w, i));
+              const uint4 of = make_uint4(rdlane(own.x, fd), rdlane(own.y, fd), rdlane(own.z, fd),
+                                          rdlane(own.w, fd));
+              ml = prefix16(of, oi);
+            } else {
+              v = (OK >> fd) & 1;
+              cnd = rdlane(old, fd) - 1;
+              ml = (int)rdlane((uint32_t)mlen, fd);
+            }
+            T |= 1ull << fd;
+            if (v) {
+              f = fd;
+              cand = cnd;
+              have = ml;
+              break;
+            }
+            rem &= ~lanes_upto(fd);
+          }
+
+          if (f == 64) {
+            if (scan_ended) {  // the scan ran into s_limit: emit_remainder (:152-159)
+              INS |= T | a_ins;
+              done = true;
+            } else if (a == 0) {  // 47 probes without a candidate: continue as a sparse scan
+              INS |= T | a_ins;
+              sparse = true;
+              scan_base = s + 1;
+              e_idx = 47;
+            }  // else: partial event at the end of the batch; redo it in a fresh batch
+            break;
+          }
+          INS |= T | a_ins;
+          const int pf = B + f;
+          int total;
+          if (have < 16)
+            total = (!P.compat_go && cand + 4 < W) ? 4 : have;
+          else
+            total = extend_match(src, g.stream, W, n, pf, cand, 16, P.compat_go, lane);
+          if (lane == 0)
+            mout[nm] = make_uint2((uint32_t)pf, kMatchType | ((uint32_t)(total - 3) << kLengthShift) |
+                                                    ((W + (uint32_t)pf) - cand - 1));
+          ++nm;
+          sumlen += (uint32_t)total;
+          s = pf + total;
+          if (s >= s_limit) {
+            done = true;
+            break;
+          }
+          a = s - 1 - B;
+          if (a > kDenseKeep) break;
+        }
+        // commit: slots of non-DUP lanes already hold their position (speculative write);
+        // un-inserted lanes and every DUP lane restore the old value, then the inserted DUP
+        // lanes write in position order so that the latest one wins.
+        if (e1 && (((DUP | ~INS) >> lane) & 1)) vtable[h] = (E)old;
+        uint64_t dm = DUP & INS;
+        while (dm) {
+          const int k = __builtin_ctzll(dm);
+          if (lane == k) vtable[h] = (E)A1;
+          dm &= dm - 1;
         }
       } else {
-        e = e_idx + lane;
+        // =============================== sparse batch ==============================
+        const int e = e_idx + lane;
+        int p, step;
         if (e < kScanClosedForm) {
           p = scan_base + scan_off_small(e, &step);
         } else {
-          int ec = e < P.scan_len - 1 ? e : P.scan_len - 2;
-          int o0 = scan_tab[ec], o1 = scan_tab[ec + 1];
+          const int ec = e < P.scan_len - 1 ? e : P.scan_len - 2;
+          const int o0 = scan_tab[ec], o1 = scan_tab[ec + 1];
           p = scan_base + o0 + (e - ec) * 65536;  // beyond the table => never exists
           step = o1 - o0;
         }
-      }
-      const bool exists = p + step <= s_limit;  // the `next_s > s_limit` test of :188
-      const uint64_t exm = __ballot(exists);
-      const int nexist = __popcll(exm);  // events are a prefix of the lanes
-      if (nexist == 0) break;            // emit_remainder (:152-159)
+        const bool exists = p + step <= s_limit;  // the `next_s > s_limit` test of :188
+        const int nexist = __popcll(__ballot(exists));  // events are a prefix of the lanes
+        if (nexist == 0) break;                         // emit_remainder (:152-159)
 
-      // ---- probe: hash, table read, candidate check -----------------------------
-      uint32_t cv = 0, h = 0, old = 0;
-      if (exists) {
-        cv = ld32(src + p);
-        h = hash4(cv);
-        old = vtable[h];
-      }
-      const uint32_t A1 = W + (uint32_t)p + 1;
-      bool ok = false;
-      if (exists && probe && old != 0 && (A1 - old) <= (uint32_t)kMaxMatchOffset)
-        ok = ld32(g.stream + (old - 1)) == cv;
-      const uint64_t V = __ballot(ok);
-      const int f0 = V ? __builtin_ctzll(V) : 64;
+        uint32_t cv = 0, h = 0, old = 0;
+        if (exists) {
+          cv = ld32(src + p);
+          h = hash4(cv);
+          old = vtable[h];
+        }
+        const uint32_t A1 = W + (uint32_t)p + 1;
+        bool ok = false;
+        if (exists && old != 0 && (A1 - old) <= (uint32_t)kMaxMatchOffset)
+          ok = ld32(g.stream + (old - 1)) == cv;
+        const uint64_t V = __ballot(ok);
+        const int f0 = ffs64(V);
 
-      // ---- commit the inserts of lanes <= first valid lane; detect collisions ----
-      const int lim = f0 < nexist - 1 ? f0 : nexist - 1;
-      const bool ins = lane <= lim;
-      if (ins) vtable[h] = (E)A1;
-      const E rb = ins ? vtable[h] : (E)A1;
-      const uint64_t C = __ballot(rb != (E)A1);
+        // commit the inserts of lanes <= first valid lane; detect same-slot collisions
+        const int lim = f0 < nexist - 1 ? f0 : nexist - 1;
+        const bool ins = lane <= lim;
+        if (ins) vtable[h] = (E)A1;
+        const uint32_t rb = ins ? (uint32_t)vtable[h] : (A1 & kEMask);
+        const uint64_t C = __ballot(rb != (A1 & kEMask));
 
-      int f = f0;
-      uint32_t cand1 = 0;  // candidate position + 1
-      if (C == 0) {
-        if (f0 < 64) cand1 = rdlane(old, f0);
-      } else {
-        // Two lanes of this batch share a slot: replay the batch in order.
-        if (ins) vtable[h] = (E)old;
-        f = 64;
-        for (int e2 = 0; e2 < nexist; ++e2) {
-          const uint32_t he = rdlane(h, e2);
-          const uint32_t pe1 = rdlane(A1, e2);
-          const uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)vtable[he]);
-          vtable[he] = (E)pe1;
-          if (post && e2 == 0) continue;  // insert-only event (s-1)
-          bool v;
-          if (cur == rdlane(old, e2)) {
-            v = (V >> e2) & 1;
-          } else {
-            // candidate was inserted by an earlier lane of this batch
-            const uint64_t m = __ballot(exists && A1 == cur);
-            v = false;
-            if (m) v = rdlane(cv, __builtin_ctzll(m)) == rdlane(cv, e2);
-          }
-          if (v) {
-            f = e2;
-            cand1 = cur;
-            break;
+        int f = f0;
+        uint32_t cand1 = 0;  // candidate position + 1
+        if (C == 0) {
+          if (f0 < 64) cand1 = rdlane(old, f0);
+        } else {
+          // two lanes of this batch share a slot: replay the batch in order
+          if (ins) vtable[h] = (E)old;
+          f = 64;
+          for (int e2 = 0; e2 < nexist; ++e2) {
+            const uint32_t he = rdlane(h, e2);
+            const uint32_t pe1 = rdlane(A1, e2);
+            const uint32_t cur =
+                (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)vtable[he]);
+            vtable[he] = (E)pe1;
+            bool v;
+            if (cur == rdlane(old, e2)) {
+              v = (V >> e2) & 1;
+            } else {  // candidate was inserted by an earlier lane of this batch
+              const uint64_t m = __ballot(exists && (A1 & kEMask) == cur);
+              v = false;
+              if (m) v = rdlane(cv, __builtin_ctzll(m)) == rdlane(cv, e2);
+            }
+            if (v) {
+              f = e2;
+              cand1 = cur;
+              break;
+            }
           }
         }
-      }
-
-      if (f == 64) {  // no candidate in this batch
-        if (nexist < 64) break;
-        if (post) {
-          post = false;
-          scan_base = s + 1;
-          e_idx = 62;
-        } else {
+        if (f == 64) {
+          if (nexist < 64) break;
           e_idx += 64;
+          continue;
         }
-        continue;
+        const int pf = (int)rdlane((uint32_t)p, f);
+        uint32_t cand = cand1 - 1;
+        if (sizeof(E) == 2) cand &= 0xffffu;
+        const int total = extend_match(src, g.stream, W, n, pf, cand, 4, P.compat_go, lane);
+        if (lane == 0)
+          mout[nm] = make_uint2((uint32_t)pf, kMatchType | ((uint32_t)(total - 3) << kLengthShift) |
+                                                  ((W + (uint32_t)pf) - cand - 1));
+        ++nm;
+        sumlen += (uint32_t)total;
+        s = pf + total;
+        sparse = false;
+        if (s >= s_limit) done = true;
       }
-
-      // ---- match at lane f: extend (match_len, :286-342) -------------------------
-      const int pf = (int)rdlane((uint32_t)p, f);
-      const uint32_t Ac = cand1 - 1;  // absolute candidate position
-      const int s2 = pf + 4;
-      int limit = n - s2;
-      if (limit > kMaxMatchTail) limit = kMaxMatchTail;
-      int l = 0;
-      if (limit > 0 && (P.compat_go || Ac + 4 >= W)) {
-        const int o = 4 * lane;
-        uint32_t x = 0;
-        if (o < limit) {
-          const int r = limit - o;
-          const uint8_t *pa = src + s2 + o, *pb = g.stream + Ac + 4 + o;
-          if (r >= 4) {
-            x = ld32(pa) ^ ld32(pb);
-          } else {
-            x = ld_partial(pa, r) ^ ld_partial(pb, r);
-          }
-        }
-        const uint64_t mm = __ballot(x != 0);
-        if (mm) {
-          const int k = __builtin_ctzll(mm);
-          const uint32_t xk = rdlane(x, k);
-          l = 4 * k + (__builtin_ctz(xk) >> 3);
-        } else {
-          l = limit;
-        }
-      }
-      if (lane == 0)
-        mout[nm] = make_uint2((uint32_t)pf, kMatchType | ((uint32_t)(l + 1) << kLengthShift) |
-                                                ((W + (uint32_t)pf) - Ac - 1));
-      ++nm;
-      sumlen += (uint32_t)l + 4;
-      s = s2 + l;
-      if (s >= s_limit) break;
-      post = true;
     }
     if (lane == 0) {
       P.chunk_nmatch[g.chunk0 + c] = nm;
