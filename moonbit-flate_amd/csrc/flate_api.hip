@@ -40,7 +40,8 @@ struct flate_hip_ctx {
   // grow-only scratch
   DevBuf d_in, d_out, d_in_off, d_chunk_base, d_ids16, d_ids32, d_matches, d_nmatch, d_ntok;
   DevBuf d_slots, d_slot_off, d_out_len, d_out_off, d_status;
-  DevBuf d_istatus, d_ierr;
+  DevBuf d_istatus, d_ierr, d_debug;
+  uint32_t debug_chunks = 0;
 };
 
 namespace {
@@ -179,6 +180,13 @@ int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, cons
   P.chunk_nmatch = (uint32_t *)c->d_nmatch.p;
   P.chunk_ntok = (uint32_t *)c->d_ntok.p;
   P.compat_go = (flags & FLATE_HIP_COMPAT_GO) ? 1u : 0u;
+  P.debug = nullptr;
+#ifdef FLATE_LZ_STAMPS
+  if ((rc = ensure(c, c->d_debug, (size_t)pl.n_chunks * 64 + 64))) return rc;
+  HIP_TRY(c, hipMemsetAsync(c->d_debug.p, 0, (size_t)pl.n_chunks * 64, c->stream));
+  P.debug = (uint64_t *)c->d_debug.p;
+  c->debug_chunks = pl.n_chunks;
+#endif
   {
     StageTimer t(c, FLATE_HIP_STAGE_LZ77);
     if (flags & FLATE_HIP_LZ_SERIAL) {
@@ -278,7 +286,7 @@ void flate_hip_destroy(flate_hip_ctx *c) {
   for (DevBuf *b : {&c->scan_tab, &c->d_in, &c->d_out, &c->d_in_off, &c->d_chunk_base, &c->d_ids16,
                     &c->d_ids32, &c->d_matches, &c->d_nmatch, &c->d_ntok, &c->d_slots,
                     &c->d_slot_off, &c->d_out_len, &c->d_out_off, &c->d_status, &c->d_istatus,
-                    &c->d_ierr})
+                    &c->d_ierr, &c->d_debug})
     release(*b);
   for (auto &e : c->ev)
     if (e) (void)hipEventDestroy(e);
@@ -427,6 +435,15 @@ int flate_hip_lz77_matches(flate_hip_ctx *c, const uint8_t *in, const uint64_t *
   const bool used[FLATE_HIP_STAGE_COUNT] = {true, false, false, false};
   return collect_timing(c, used);
 }
+
+#ifdef FLATE_LZ_STAMPS
+// diagnostic builds only: per-chunk phase cycle sums of the last match-finder launch
+int flate_hip_debug_lz_stamps(flate_hip_ctx *c, uint64_t *out, uint32_t max_chunks) {
+  uint32_t k = c->debug_chunks < max_chunks ? c->debug_chunks : max_chunks;
+  if (hipMemcpy(out, c->d_debug.p, (size_t)k * 64, hipMemcpyDeviceToHost) != hipSuccess) return -3;
+  return (int)k;
+}
+#endif
 
 int flate_hip_inflate_batch(flate_hip_ctx *c, const uint8_t *in, const uint64_t *in_off, uint32_t n,
                             uint8_t *out, const uint64_t *out_off, uint64_t *out_len,

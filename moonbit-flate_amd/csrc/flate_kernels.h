@@ -20,6 +20,7 @@ struct LzParams {
   uint32_t *chunk_nmatch;  // per chunk
   uint32_t *chunk_ntok;    // per chunk: literals + matches (DeflateFast::encode's token count)
   uint32_t compat_go;
+  uint64_t *debug;  // diagnostic builds only (8 u64 per chunk), else null
 };
 
 struct HuffParams {

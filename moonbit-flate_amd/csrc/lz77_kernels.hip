@@ -174,6 +174,15 @@ __global__ __launch_bounds__(64) void lz77_serial_kernel(LzParams P) {
 // ---------------------------------------------------------------------------------
 constexpr int kDenseKeep = 46;  // keep using a dense batch while the next s-1 lane <= this
 
+// Diagnostic build only (-DFLATE_LZ_STAMPS): per-chunk s_memtime sums of the batch phases.
+#ifdef FLATE_LZ_STAMPS
+#define STAMP(var) const uint64_t var = __builtin_amdgcn_s_memtime()
+#define STAMP_ADD(acc, t1, t0) acc += (t1) - (t0)
+#else
+#define STAMP(var)
+#define STAMP_ADD(acc, t1, t0)
+#endif
+
 FLATE_D uint64_t lanes_below(int l) { return l >= 64 ? ~0ull : ((1ull << l) - 1ull); }
 FLATE_D uint64_t lanes_upto(int l) { return l >= 63 ? ~0ull : ((1ull << (l + 1)) - 1ull); }
 FLATE_D int ffs64(uint64_t m) { return m ? __builtin_ctzll(m) : 64; }
@@ -229,6 +238,7 @@ __global__ __launch_bounds__(64) void lz77_wave_kernel(LzParams P) {
 
   const ChunkGeom g = stream_geom(P, sid);
   const uint16_t *scan_tab = P.scan_off;
+  uint32_t pf_val = 0, pf_sink = 0;
 
   for (uint32_t c = 0; c < g.nchunks; ++c) {
     const uint32_t W = c * (uint32_t)kMaxStoreBlockSize;
@@ -236,17 +246,22 @@ __global__ __launch_bounds__(64) void lz77_wave_kernel(LzParams P) {
     const int n = rem_len < (uint64_t)kMaxStoreBlockSize ? (int)rem_len : kMaxStoreBlockSize;
     const uint8_t *src = g.stream + W;
     uint2 *mout = P.matches + g.mbase + (uint64_t)c * kMatchCapPerChunk;
-    uint32_t nm = 0, sumlen = 0;
+    uint32_t nm = 0;
+    uint32_t acc_len = 0;  // per-lane partial sums of match lengths
     const int s_limit = n - kInputMargin;
 
     int s = -1;
     bool sparse = false;
     int scan_base = 0, e_idx = 0;
     bool done = false;
+#ifdef FLATE_LZ_STAMPS
+    uint64_t st_load = 0, st_dup = 0, st_ev = 0, st_commit = 0, st_sparse = 0, st_nb = 0, st_ext = 0;
+#endif
 
     while (!done) {
       if (!sparse) {
         // =============================== dense batch ===============================
+        STAMP(t0);
         const int B = s - 1;
         const int q = B + lane;
         const bool e1 = q >= 0 && q + 1 <= s_limit;  // may be inserted / probed with step 1
@@ -255,17 +270,27 @@ __global__ __launch_bounds__(64) void lz77_wave_kernel(LzParams P) {
         const uint32_t A1 = W + (uint32_t)q + 1;
         uint4 own = make_uint4(0, 0, 0, 0);
         uint32_t h = 0, old = 0;
+        pf_sink ^= pf_val;  // retire the previous batch's look-ahead load
         if (e1) {
           own = ld128(src + q);
           h = hash4(own.x);
-          old = vtable[h];
+          old = table[h];
         }
         const bool inr = e1 && old != 0 && (A1 - old) <= (uint32_t)kMaxMatchOffset;
         uint4 cb = own;
         if (inr) cb = ld128(g.stream + (old - 1));
+        {  // look-ahead: pull the next lines of this stream towards L2.  Issued after the
+           // candidate gather so that no wait of this batch has to include it.
+          int pq = B + 768 + 4 * lane;
+          if (pq > n - 4) pq = n - 4;
+          pf_val = ld32(src + pq);
+        }
         // duplicate-slot detection: speculative insert of all 64 positions + read-back
-        if (e1) vtable[h] = (E)A1;
-        const uint32_t rb = e1 ? (uint32_t)vtable[h] : (A1 & kEMask);
+        asm volatile("" ::: "memory");
+        if (e1) table[h] = (E)A1;
+        asm volatile("" ::: "memory");
+        const uint32_t rb = e1 ? (uint32_t)table[h] : (A1 & kEMask);
+        asm volatile("" ::: "memory");
         const bool loser = rb != (A1 & kEMask);
         const uint64_t LM = __ballot(loser);
         uint64_t DUP = LM;
@@ -278,12 +303,52 @@ __global__ __launch_bounds__(64) void lz77_wave_kernel(LzParams P) {
             m &= ~__ballot(loser && wl == w);
           }
         }
+        STAMP(t1);
         const int mlen = inr ? prefix16(own, cb) : 0;
         const uint64_t OK = __ballot(mlen >= 4);
+        // per-lane facts about "a match at my position against my slot's old value"
+        const bool cross = !P.compat_go && old + 3 < W;         // (old-1)+4 < W: MoonBit prev is empty
+        const int tot_self = cross ? 4 : mlen;                   // 16 => needs extension (slow)
+        uint32_t rec_tok = kMatchType | ((uint32_t)(tot_self - 3) << kLengthShift) | (A1 - old - 1);
+        // speculative evaluation of the event that would start with s-1 == my lane
+        uint32_t ev;       // [6:0] match lane, [15:8] total length, bit16 slow, bit17 chunk ends
+        uint64_t insm;     // lanes inserted by that event
+        {
+          const int bsh = lane + 2;
+          const uint64_t scanR = ((0x00000000ffffffffull << bsh) & E1) |
+                                 ((0x5555555500000000ull << bsh) & E2);
+          const uint64_t R = (E1 & (2ull << lane)) | scanR;
+          const uint64_t okR = OK & R & ~DUP, dupR = DUP & R;
+          const int fv = okR ? __builtin_ctzll(okR) : 64;
+          const int fd = dupR ? __builtin_ctzll(dupR) : 64;
+          const int tf = __shfl(tot_self, fv & 63);
+          const bool slow = !(fv < fd) || tf >= 16;
+          const bool ends = B + fv + tf >= s_limit;
+          ev = (uint32_t)(fv & 127) | ((uint32_t)tf << 8) | (slow ? 1u << 16 : 0u) | (ends ? 1u << 17 : 0u);
+          insm = (R & lanes_upto(fv & 63)) | (E1 & (1ull << lane));
+        }
+        STAMP(t2);
 
-        uint64_t INS = 0;
+        uint64_t INS = 0, M = 0, MF = 0;  // inserted lanes, match lanes, match lanes of fast events
         int a = 0;
         for (;;) {  // events inside this batch
+          const uint32_t x = rdlane(ev, a);
+          if (!(x & (1u << 16))) {
+            // fast event: first valid probe lane has a private slot and a < 16-byte match
+            const int fv = (int)(x & 127u), tf = (int)((x >> 8) & 255u);
+            INS |= (uint64_t)rdlane((uint32_t)insm, a) | ((uint64_t)rdlane((uint32_t)(insm >> 32), a) << 32);
+            M |= 1ull << fv;
+            MF |= 1ull << fv;
+            s = B + fv + tf;
+            if (x & (1u << 17)) {
+              done = true;
+              break;
+            }
+            a = fv + tf - 1;
+            if (a > kDenseKeep) break;
+            continue;
+          }
+          // ---- general event (shared slots, long matches, end of scan) ----
           const uint64_t a_ins = E1 & (1ull << a);
           const int b = a + 2;
           const uint64_t full = 0x55555555ffffffffull << b;  // scan probe lanes (steps 1 then 2)
@@ -358,11 +423,11 @@ __global__ __launch_bounds__(64) void lz77_wave_kernel(LzParams P) {
             total = (!P.compat_go && cand + 4 < W) ? 4 : have;
           else
             total = extend_match(src, g.stream, W, n, pf, cand, 16, P.compat_go, lane);
-          if (lane == 0)
-            mout[nm] = make_uint2((uint32_t)pf, kMatchType | ((uint32_t)(total - 3) << kLengthShift) |
-                                                    ((W + (uint32_t)pf) - cand - 1));
-          ++nm;
-          sumlen += (uint32_t)total;
+          M |= 1ull << f;
+          if (lane == f) {
+            rec_tok = kMatchType | ((uint32_t)(total - 3) << kLengthShift) | ((W + (uint32_t)pf) - cand - 1);
+            acc_len += (uint32_t)total;
+          }
           s = pf + total;
           if (s >= s_limit) {
             done = true;
@@ -371,16 +436,33 @@ __global__ __launch_bounds__(64) void lz77_wave_kernel(LzParams P) {
           a = s - 1 - B;
           if (a > kDenseKeep) break;
         }
+        STAMP(t3);
+        // match records of this batch, in position order, one coalesced store
+        if ((MF >> lane) & 1) acc_len += (uint32_t)tot_self;
+        if ((M >> lane) & 1)
+          mout[nm + (uint32_t)__popcll(M & lanes_below(lane))] = make_uint2((uint32_t)q, rec_tok);
+        nm += (uint32_t)__popcll(M);
         // commit: slots of non-DUP lanes already hold their position (speculative write);
         // un-inserted lanes and every DUP lane restore the old value, then the inserted DUP
         // lanes write in position order so that the latest one wins.
-        if (e1 && (((DUP | ~INS) >> lane) & 1)) vtable[h] = (E)old;
+        asm volatile("" ::: "memory");
+        if (e1 && (((DUP | ~INS) >> lane) & 1)) table[h] = (E)old;
         uint64_t dm = DUP & INS;
         while (dm) {
           const int k = __builtin_ctzll(dm);
-          if (lane == k) vtable[h] = (E)A1;
+          asm volatile("" ::: "memory");
+          if (lane == k) table[h] = (E)A1;
           dm &= dm - 1;
         }
+        asm volatile("" ::: "memory");
+        STAMP(t4);
+        STAMP_ADD(st_dup, t1, t0);
+        STAMP_ADD(st_load, t2, t1);
+        STAMP_ADD(st_ev, t3, t2);
+        STAMP_ADD(st_commit, t4, t3);
+#ifdef FLATE_LZ_STAMPS
+        st_nb += 1;
+#endif
       } else {
         // =============================== sparse batch ==============================
         const int e = e_idx + lane;
@@ -459,15 +541,25 @@ __global__ __launch_bounds__(64) void lz77_wave_kernel(LzParams P) {
           mout[nm] = make_uint2((uint32_t)pf, kMatchType | ((uint32_t)(total - 3) << kLengthShift) |
                                                   ((W + (uint32_t)pf) - cand - 1));
         ++nm;
-        sumlen += (uint32_t)total;
+        if (lane == 0) acc_len += (uint32_t)total;
         s = pf + total;
         sparse = false;
         if (s >= s_limit) done = true;
       }
     }
+    uint32_t sumlen = acc_len;
+    for (int d = 32; d >= 1; d >>= 1) sumlen += __shfl_xor(sumlen, d);
+    if (pf_sink == 0x9e3779b9u && P.debug) P.debug[0] = pf_sink;  // keeps the look-ahead loads alive
     if (lane == 0) {
       P.chunk_nmatch[g.chunk0 + c] = nm;
       P.chunk_ntok[g.chunk0 + c] = (uint32_t)n - sumlen + nm;
+#ifdef FLATE_LZ_STAMPS
+      if (P.debug) {
+        uint64_t *d = P.debug + (uint64_t)(g.chunk0 + c) * 8;
+        d[0] = st_dup; d[1] = st_load; d[2] = st_ev; d[3] = st_commit; d[4] = st_nb; d[5] = nm;
+        d[6] = st_ext; d[7] = st_sparse;
+      }
+#endif
     }
   }
 }
