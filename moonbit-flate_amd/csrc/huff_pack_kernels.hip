@@ -45,14 +45,14 @@ struct Shared {
   uint16_t ssym[288];
   uint32_t lv[2][576];  // package-merge level lists (ping-pong)
   uint32_t pairs[288];
-  uint16_t leaf_rank[16][288];
+  uint32_t leaf_bits[16][18];  // per level: bit r set <=> item r of the merged list is a leaf
   uint8_t slen[288];
   uint32_t counts[17];
   uint32_t first_code[17];
   uint32_t len_base[17];
   // header
   uint8_t codegen[320];
-  uint32_t hdr_val[kHdrMax];
+  uint16_t hdr_val[kHdrMax];
   uint8_t hdr_nb[kHdrMax];
   uint32_t hdr_n;
   uint32_t ring[kRing];
@@ -61,21 +61,25 @@ struct Shared {
 FLATE_D uint32_t rdlane(uint32_t v, int lane) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
 }
-FLATE_D uint32_t wave_sum(uint32_t v) {
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+// DPP row shifts / row broadcasts (gfx9): wave64 inclusive prefix sum without LDS traffic.
+template <int CTRL, int ROW_MASK>
+FLATE_D uint32_t dpp_add(uint32_t v) {
+  return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+FLATE_D uint32_t wave_incl_scan(uint32_t v) {
+  v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_add<0x118, 0xf>(v);  // row_shr:8
+  v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 -> rows 1,3
+  v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 -> rows 2,3
   return v;
 }
+FLATE_D uint32_t wave_sum(uint32_t v) { return rdlane(wave_incl_scan(v), 63); }
 FLATE_D uint32_t wave_max(uint32_t v) {
   for (int d = 32; d >= 1; d >>= 1) {
     uint32_t o = __shfl_xor(v, d);
     v = o > v ? o : v;
-  }
-  return v;
-}
-FLATE_D uint32_t wave_incl_scan(uint32_t v, int lane) {
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t o = __shfl_up(v, d);
-    if (lane >= d) v += o;
   }
   return v;
 }
@@ -90,7 +94,7 @@ struct BitSink {
 
 // Every lane appends nb (<= 48) bits, in lane order.
 FLATE_D void sink_emit(BitSink &S, uint64_t bits, uint32_t nb, int lane) {
-  const uint32_t incl = wave_incl_scan(nb, lane);
+  const uint32_t incl = wave_incl_scan(nb);
   const uint32_t total = rdlane(incl, 63);
   if (nb) {
     const uint64_t q = S.bitpos + (incl - nb);
@@ -189,10 +193,8 @@ FLATE_D void build_code(Shared &sh, const uint32_t *freq, int nsym, int max_bits
   const int mb = max_bits < n - 1 ? max_bits : n - 1;  // :126-129
 
   // level 1: the leaves themselves
-  for (int i = lane; i < n; i += 64) {
-    sh.lv[0][i] = sh.sfreq[i];
-    sh.leaf_rank[1][i] = (uint16_t)i;
-  }
+  for (int i = lane; i < n; i += 64) sh.lv[0][i] = sh.sfreq[i];
+  for (int i = lane; i < 16 * 18; i += 64) (&sh.leaf_bits[0][0])[i] = 0;
   __syncthreads();
   int lp = n;  // length of the previous level's list
   int cur = 0;
@@ -215,7 +217,7 @@ FLATE_D void build_code(Shared &sh, const uint32_t *freq, int nsym, int max_bits
       }
       const int r = i + lo;
       next[r] = f;
-      sh.leaf_rank[lvl][i] = (uint16_t)r;
+      atomicOr(&sh.leaf_bits[lvl][r >> 5], 1u << (r & 31));
     }
     // pairs: rank = j + #leaves with freq < sum
     for (int j = lane; j < np; j += 64) {
@@ -239,10 +241,18 @@ FLATE_D void build_code(Shared &sh, const uint32_t *freq, int nsym, int max_bits
   {
     uint32_t m = 2u * (uint32_t)n - 2u;
     for (int lvl = mb; lvl >= 1; --lvl) {
-      uint32_t a = 0;
-      for (int base = 0; base < n; base += 64) {
-        const int i = base + lane;
-        a += __popcll(__ballot(i < n && (uint32_t)sh.leaf_rank[lvl][i] < m));
+      uint32_t a;
+      if (lvl == 1) {
+        a = m < (uint32_t)n ? m : (uint32_t)n;  // level 1 holds only leaves
+      } else {
+        uint32_t part = 0;
+        if (lane < 18) {
+          const uint32_t wbits = sh.leaf_bits[lvl][lane];
+          const int lo = lane * 32;
+          const uint32_t keep = (int)m >= lo + 32 ? 0xffffffffu : ((int)m <= lo ? 0u : ((1u << (m - lo)) - 1u));
+          part = __popc(wbits & keep);
+        }
+        a = wave_sum(part);
       }
       if (lane == 0) sh.counts[lvl] = a;
       m = 2u * (m - a);
@@ -305,15 +315,42 @@ struct Walker {
   int n;
   uint32_t mp;         // next match record
   uint32_t cov_until;  // positions < cov_until are covered by an earlier match
+  // software pipeline: data of the tile about to be processed, loaded one tile ahead
+  uint2 rec;           // lanes 0..31: recs[mp + lane]
+  uint32_t byte;       // src[P0 + lane]
 };
+
+FLATE_D uint2 load_rec(const Walker &w, uint32_t mp, int lane) {
+  uint2 r = make_uint2(0xffffffffu, 0);
+  if (lane < 32 && mp + (uint32_t)lane < w.nm) r = w.recs[mp + lane];
+  return r;
+}
+FLATE_D uint32_t load_byte(const Walker &w, int pos) { return pos < w.n ? w.src[pos] : 0u; }
+
+FLATE_D Walker walker_init(const uint8_t *src, const uint2 *recs, uint32_t nm, int n, int lane) {
+  Walker w;
+  w.src = src;
+  w.recs = recs;
+  w.nm = nm;
+  w.n = n;
+  w.mp = 0;
+  w.cov_until = 0;
+  w.rec = load_rec(w, 0, lane);
+  w.byte = load_byte(w, lane);
+  return w;
+}
 
 FLATE_D TileTok walk_tile(Walker &w, int P0, int lane) {
   TileTok t;
   const int pos = P0 + lane;
-  uint2 rec = make_uint2(0xffffffffu, 0);
-  if (lane < 16 && w.mp + (uint32_t)lane < w.nm) rec = w.recs[w.mp + lane];
-  const uint64_t mine = __ballot(rec.x < (uint32_t)(P0 + 64));
+  const uint2 rec = w.rec;
+  const uint32_t byte = w.byte;
+  const uint64_t mine = __ballot(rec.x < (uint32_t)(P0 + 64));  // <= 16 matches start in a tile
   const int cnt = __popcll(mine);
+  // issue the next tile's loads now; they are consumed one iteration later
+  w.mp += (uint32_t)cnt;
+  w.rec = load_rec(w, w.mp, lane);
+  w.byte = load_byte(w, pos + 64);
   bool covered = (uint32_t)pos < w.cov_until;
   uint32_t tok = 0;
   for (int k = 0; k < cnt; ++k) {
@@ -325,9 +362,8 @@ FLATE_D TileTok walk_tile(Walker &w, int P0, int lane) {
       covered = true;
     if (k == cnt - 1) w.cov_until = pk + lk;
   }
-  w.mp += (uint32_t)cnt;
   const bool active = pos < w.n;
-  t.byte = active ? w.src[pos] : 0u;
+  t.byte = byte;
   t.is_match = active && tok != 0;
   t.is_lit = active && !covered && tok == 0;
   t.tok = tok;
@@ -465,9 +501,14 @@ FLATE_D void block_huff(Shared &sh, BitSink &S, const HuffParams &P, const uint8
                         int lane) {
   for (int i = lane; i < 288; i += 64) sh.lit_freq[i] = 0;
   __syncthreads();
-  for (int base = 0; base < n; base += 64) {
-    const int i = base + lane;
-    if (i < n) atomicAdd(&sh.lit_freq[src[i]], 1u);
+  {
+    uint32_t nxt = lane < n ? src[lane] : 0u;
+    for (int base = 0; base < n; base += 64) {
+      const int i = base + lane;
+      const uint32_t bt = nxt;
+      nxt = i + 64 < n ? src[i + 64] : 0u;
+      if (i < n) atomicAdd(&sh.lit_freq[bt], 1u);
+    }
   }
   __syncthreads();
   if (lane == 0) sh.lit_freq[kEndBlockMarker] = 1;
@@ -485,11 +526,15 @@ FLATE_D void block_huff(Shared &sh, BitSink &S, const HuffParams &P, const uint8
     return;
   }
   emit_items(sh, S, lane);
-  for (int base = 0; base < n; base += 64) {
-    const int i = base + lane;
-    uint32_t c = 0;
-    if (i < n) c = sh.lit_cl[src[i]];
-    sink_emit(S, c & 0xffffu, c >> 16, lane);
+  {
+    uint32_t nxt = lane < n ? src[lane] : 0u;
+    for (int base = 0; base < n; base += 64) {
+      const int i = base + lane;
+      const uint32_t bt = nxt;
+      nxt = i + 64 < n ? src[i + 64] : 0u;
+      const uint32_t c = i < n ? sh.lit_cl[bt] : 0u;
+      sink_emit(S, c & 0xffffu, c >> 16, lane);
+    }
   }
   const uint32_t eob = sh.lit_cl[kEndBlockMarker];
   sink_emit(S, eob & 0xffffu, lane == 0 ? (eob >> 16) : 0u, lane);
@@ -503,7 +548,7 @@ FLATE_D void block_dynamic(Shared &sh, BitSink &S, const HuffParams &P, const ui
   __syncthreads();
   // index_tokens (:550-593)
   {
-    Walker w = {src, recs, nm, n, 0u, 0u};
+    Walker w = walker_init(src, recs, nm, n, lane);
     for (int P0 = 0; P0 < n; P0 += 64) {
       const TileTok t = walk_tile(w, P0, lane);
       if (t.is_match) {
@@ -547,7 +592,7 @@ FLATE_D void block_dynamic(Shared &sh, BitSink &S, const HuffParams &P, const ui
   }
   emit_items(sh, S, lane);
   // write_tokens (:596-731)
-  Walker w = {src, recs, nm, n, 0u, 0u};
+  Walker w = walker_init(src, recs, nm, n, lane);
   for (int P0 = 0; P0 < n; P0 += 64) {
     const TileTok t = walk_tile(w, P0, lane);
     uint64_t bits = 0;
