@@ -75,22 +75,15 @@ def main():
     out = torch.empty(in_bytes + (in_bytes >> 3) + 4096, dtype=torch.uint8, device=dev)
 
     gather = (world > 1) and not args.no_gather
-    gbuf = None
-    sizes_all = None
+    shard = importlib.import_module("moonbit-flate_amd.shard")
+    gathered = None
 
     def step():
-        nonlocal gbuf, sizes_all
+        nonlocal gathered
         _, out_off = eng.deflate_batch(d_in, in_off, out=out)
-        clen = int(out_off[-1])
-        if gather:
-            sz = torch.tensor([clen], dtype=torch.int64, device=dev)
-            szs = torch.empty(world, dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(szs, sz)
-            sizes_all = szs.cpu().numpy()
-            pad = (int(sizes_all.max()) + (1 << 20) - 1) & ~((1 << 20) - 1)
-            if gbuf is None or gbuf.numel() < pad * world:
-                gbuf = torch.empty(pad * world, dtype=torch.uint8, device=dev)
-            dist.all_gather_into_tensor(gbuf[:pad * world], out[:pad])
+        if gather:  # north_star's exchange step: every rank ends up with every compressed shard
+            gathered = shard.gather_compressed(dist, out, out_off,
+                                               buf=None if gathered is None else gathered.buf)
         return out_off
 
     def sync_all():

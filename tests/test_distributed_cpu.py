@@ -1,0 +1,79 @@
+"""World-size-2 gloo test (CPU) of the multi-GPU row: contiguous sharding of streams, the
+all-gather concatenation of the compressed shards and the global stream index.  The compress step
+itself has no CPU path in the product, so each rank's shard is produced by the oracle here."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_streams, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import importlib
+    import torch
+    import torch.distributed as dist
+    from oracle import pyoracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    flate = importlib.import_module("moonbit-flate_amd")
+    shard = importlib.import_module("moonbit-flate_amd.shard")
+    lo, hi = shard.shard_range(n_streams, rank, world)
+    lens = [3000 + 977 * j for j in range(n_streams)]          # ragged streams
+    streams = [flate.synth("text", 1, lens[j], first_stream=j) for j in range(lo, hi)]
+    comp = [np.frombuffer(pyoracle.deflate(s), dtype=np.uint8) for s in streams]
+    off = np.zeros(len(comp) + 1, dtype=np.uint64)
+    np.cumsum([c.size for c in comp], out=off[1:])
+    local = torch.from_numpy(np.concatenate(comp).copy())
+    g = shard.gather_compressed(dist, local, off, pad_to=4096)
+    ok = True
+    # every rank must now hold every stream, in global order, bit-exact
+    for j in range(n_streams):
+        want = pyoracle.deflate(flate.synth("text", 1, lens[j], first_stream=j))
+        got = bytes(g.stream(j).numpy())
+        ok = ok and (got == want)
+    ok = ok and int(g.counts.sum()) == n_streams and g.off.size == n_streams
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, ok, int(g.sizes.sum())))
+
+
+@pytest.mark.parametrize("n_streams", [7, 8])
+def test_two_rank_gather_of_compressed_shards(n_streams):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_streams, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    assert res[0][2] == res[1][2]
+
+
+def test_shard_range_partitions_exactly():
+    import importlib
+    sys.path.insert(0, ROOT)
+    shard = importlib.import_module("moonbit-flate_amd.shard")
+    for n in (0, 1, 7, 16384, 16385):
+        for w in (1, 2, 4, 8):
+            r = [shard.shard_range(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[k][1] == r[k + 1][0] for k in range(w - 1))
