@@ -366,6 +366,13 @@ int flate_hip_deflate_fast_batch(flate_hip_ctx *c, const uint8_t *in, const uint
   H.out_len = (uint64_t *)c->d_out_len.p;
   H.n_streams = n;
   H.compat_go = (flags & FLATE_HIP_COMPAT_GO) ? 1u : 0u;
+  H.debug = nullptr;
+#ifdef FLATE_HP_STAMPS
+  if ((rc = ensure(c, c->d_debug, (size_t)n * 64 + 64))) return rc;
+  HIP_TRY(c, hipMemsetAsync(c->d_debug.p, 0, (size_t)n * 64, c->stream));
+  H.debug = (uint64_t *)c->d_debug.p;
+  c->debug_chunks = n;
+#endif
   {
     StageTimer t(c, FLATE_HIP_STAGE_HUFF_PACK);
     hipLaunchKernelGGL(huff_pack_kernel, dim3(n), dim3(64), 0, c->stream, H);
@@ -436,7 +443,7 @@ int flate_hip_lz77_matches(flate_hip_ctx *c, const uint8_t *in, const uint64_t *
   return collect_timing(c, used);
 }
 
-#ifdef FLATE_LZ_STAMPS
+#if defined(FLATE_LZ_STAMPS) || defined(FLATE_HP_STAMPS)
 // diagnostic builds only: per-chunk phase cycle sums of the last match-finder launch
 int flate_hip_debug_lz_stamps(flate_hip_ctx *c, uint64_t *out, uint32_t max_chunks) {
   uint32_t k = c->debug_chunks < max_chunks ? c->debug_chunks : max_chunks;

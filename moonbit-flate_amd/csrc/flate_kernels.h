@@ -35,6 +35,7 @@ struct HuffParams {
   uint64_t *out_len;         // bytes produced per stream
   uint32_t n_streams;
   uint32_t compat_go;
+  uint64_t *debug;  // diagnostic builds only (8 u64 per stream), else null
 };
 
 struct CompactParams {

@@ -29,6 +29,14 @@ namespace {
 constexpr int kRing = 256;  // dwords in the LDS bit ring (a tile adds <= 96 dwords)
 constexpr int kHdrMax = 704;
 
+#ifdef FLATE_HP_STAMPS
+#define HSTAMP(var) const uint64_t var = __builtin_amdgcn_s_memtime()
+#define HSTAMP_ADD(i, t1, t0) do { if (lane == 0) sh.st[i] += (t1) - (t0); } while (0)
+#else
+#define HSTAMP(var)
+#define HSTAMP_ADD(i, t1, t0)
+#endif
+
 // codegen_order, huffman-bit-writer.mbt:83-85 (RFC 1951 3.2.7)
 __constant__ uint8_t kCodegenOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
@@ -55,7 +63,11 @@ struct Shared {
   uint16_t hdr_val[kHdrMax];
   uint8_t hdr_nb[kHdrMax];
   uint32_t hdr_n;
+  uint2 tile[64];  // per-tile scatter target: {token starting here, coverage mark +1/-1}
   uint32_t ring[kRing];
+#ifdef FLATE_HP_STAMPS
+  uint64_t st[8];
+#endif
 };
 
 FLATE_D uint32_t rdlane(uint32_t v, int lane) {
@@ -340,33 +352,38 @@ FLATE_D Walker walker_init(const uint8_t *src, const uint2 *recs, uint32_t nm, i
   return w;
 }
 
-FLATE_D TileTok walk_tile(Walker &w, int P0, int lane) {
+FLATE_D TileTok walk_tile(Shared &sh, Walker &w, int P0, int lane) {
   TileTok t;
   const int pos = P0 + lane;
   const uint2 rec = w.rec;
   const uint32_t byte = w.byte;
-  const uint64_t mine = __ballot(rec.x < (uint32_t)(P0 + 64));  // <= 16 matches start in a tile
-  const int cnt = __popcll(mine);
+  const bool mine = rec.x < (uint32_t)(P0 + 64);  // <= 16 matches start in a tile (lanes 0..15)
+  const int cnt = __popcll(__ballot(mine));
   // issue the next tile's loads now; they are consumed one iteration later
   w.mp += (uint32_t)cnt;
   w.rec = load_rec(w, w.mp, lane);
   w.byte = load_byte(w, pos + 64);
-  bool covered = (uint32_t)pos < w.cov_until;
-  uint32_t tok = 0;
-  for (int k = 0; k < cnt; ++k) {
-    const uint32_t pk = rdlane(rec.x, k), tk = rdlane(rec.y, k);
-    const uint32_t lk = ((tk >> kLengthShift) & 0xffu) + 3u;
-    if ((uint32_t)pos == pk)
-      tok = tk;
-    else if ((uint32_t)pos > pk && (uint32_t)pos < pk + lk)
-      covered = true;
-    if (k == cnt - 1) w.cov_until = pk + lk;
+  // scatter the tile's matches: token at its start position, +1 at the first covered
+  // position, -1 just past the match; a prefix sum of the marks is the coverage
+  sh.tile[lane] = make_uint2(0u, 0u);
+  __syncthreads();
+  const uint32_t mlen = ((rec.y >> kLengthShift) & 0xffu) + 3u;
+  if (mine) {
+    const uint32_t o = rec.x - (uint32_t)P0;
+    sh.tile[o].x = rec.y;
+    if (o + 1 < 64u) sh.tile[o + 1].y = 1u;
+    if (o + mlen < 64u) sh.tile[o + mlen].y = 0xffffffffu;
   }
+  __syncthreads();
+  const uint2 tl = sh.tile[lane];
+  const uint32_t cover = wave_incl_scan(tl.y);
+  const bool covered = (uint32_t)pos < w.cov_until || cover != 0;
+  if (cnt) w.cov_until = rdlane(rec.x, cnt - 1) + rdlane(mlen, cnt - 1);
   const bool active = pos < w.n;
   t.byte = byte;
-  t.is_match = active && tok != 0;
-  t.is_lit = active && !covered && tok == 0;
-  t.tok = tok;
+  t.tok = tl.x;
+  t.is_match = active && tl.x != 0;
+  t.is_lit = active && !covered && tl.x == 0;
   return t;
 }
 
@@ -543,6 +560,7 @@ FLATE_D void block_huff(Shared &sh, BitSink &S, const HuffParams &P, const uint8
 // write_block_dynamic (:496-542) over the implied token sequence of one LZ77 chunk
 FLATE_D void block_dynamic(Shared &sh, BitSink &S, const HuffParams &P, const uint8_t *src, int n,
                            const uint2 *recs, uint32_t nm, int lane) {
+  HSTAMP(h0);
   for (int i = lane; i < 288; i += 64) sh.lit_freq[i] = 0;
   if (lane < 32) sh.off_freq[lane] = 0;
   __syncthreads();
@@ -550,7 +568,7 @@ FLATE_D void block_dynamic(Shared &sh, BitSink &S, const HuffParams &P, const ui
   {
     Walker w = walker_init(src, recs, nm, n, lane);
     for (int P0 = 0; P0 < n; P0 += 64) {
-      const TileTok t = walk_tile(w, P0, lane);
+      const TileTok t = walk_tile(sh, w, P0, lane);
       if (t.is_match) {
         const CodeBits lc = length_code_of((t.tok >> kLengthShift) & 0xffu);
         const CodeBits oc = offset_code_of(t.tok & ((1u << kLengthShift) - 1u));
@@ -563,6 +581,7 @@ FLATE_D void block_dynamic(Shared &sh, BitSink &S, const HuffParams &P, const ui
     if (lane == 0) atomicAdd(&sh.lit_freq[kEndBlockMarker], 1u);  // tokens.push(EOB), :507
   }
   __syncthreads();
+  HSTAMP(h1);
   int num_literals, num_offsets;
   {
     uint32_t hi = 0;
@@ -578,8 +597,11 @@ FLATE_D void block_dynamic(Shared &sh, BitSink &S, const HuffParams &P, const ui
   }
   __syncthreads();
   build_code(sh, sh.lit_freq, kMaxNumLit, 15, sh.lit_cl, lane);
+  HSTAMP(h2);
   build_code(sh, sh.off_freq, kOffsetCodeCount, 15, sh.off_cl, lane);
+  HSTAMP(h3);
   uint32_t size = make_header(sh, num_literals, num_offsets, lane);
+  HSTAMP(h4);
   {
     uint32_t part = 0;
     for (int i = lane; i < kMaxNumLit; i += 64) part += sh.lit_freq[i] * (sh.lit_cl[i] >> 16);
@@ -591,10 +613,11 @@ FLATE_D void block_dynamic(Shared &sh, BitSink &S, const HuffParams &P, const ui
     return;
   }
   emit_items(sh, S, lane);
+  HSTAMP(h5);
   // write_tokens (:596-731)
   Walker w = walker_init(src, recs, nm, n, lane);
   for (int P0 = 0; P0 < n; P0 += 64) {
-    const TileTok t = walk_tile(w, P0, lane);
+    const TileTok t = walk_tile(sh, w, P0, lane);
     uint64_t bits = 0;
     uint32_t nb = 0;
     if (t.is_match) {
@@ -619,6 +642,13 @@ FLATE_D void block_dynamic(Shared &sh, BitSink &S, const HuffParams &P, const ui
   }
   const uint32_t eob = sh.lit_cl[kEndBlockMarker];
   sink_emit(S, eob & 0xffffu, lane == 0 ? (eob >> 16) : 0u, lane);
+  HSTAMP(h6);
+  HSTAMP_ADD(0, h1, h0);
+  HSTAMP_ADD(1, h2, h1);
+  HSTAMP_ADD(2, h3, h2);
+  HSTAMP_ADD(3, h4, h3);
+  HSTAMP_ADD(4, h5, h4);
+  HSTAMP_ADD(5, h6, h5);
 }
 
 }  // namespace
@@ -635,6 +665,10 @@ __global__ __launch_bounds__(64) void huff_pack_kernel(HuffParams P) {
   const uint32_t chunk0 = P.chunk_base[sid];
 
   for (int i = lane; i < kRing; i += 64) sh.ring[i] = 0;
+#ifdef FLATE_HP_STAMPS
+  if (lane < 8) sh.st[lane] = 0;
+  const uint64_t k0 = __builtin_amdgcn_s_memtime();
+#endif
   __syncthreads();
   BitSink S;
   S.ring = sh.ring;
@@ -668,6 +702,12 @@ __global__ __launch_bounds__(64) void huff_pack_kernel(HuffParams P) {
   emit_stored(S, stream, 0, true, lane);
   sink_finish(S, lane);
   if (lane == 0) P.out_len[sid] = S.bitpos >> 3;
+#ifdef FLATE_HP_STAMPS
+  if (lane == 0 && P.debug) {
+    sh.st[6] = __builtin_amdgcn_s_memtime() - k0;
+    for (int i = 0; i < 8; ++i) P.debug[(uint64_t)sid * 8 + i] = sh.st[i];
+  }
+#endif
 }
 
 }  // namespace flate

@@ -1,8 +1,8 @@
-"""Dev tool: run the stamped build (build/exp/libstamps.so) and print phase shares of the LZ77 kernel."""
+"""Dev tool: phase shares of huff_pack_kernel (build with -DFLATE_HP_STAMPS into build/exp/libhpstamps.so)."""
 import ctypes as C, importlib, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("FLATE_HIP_LIB", os.path.abspath("build/exp/libstamps.so"))
+os.environ.setdefault("FLATE_HIP_LIB", os.path.abspath("build/exp/libhpstamps.so"))
 flate = importlib.import_module("moonbit-flate_amd")
 import torch
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
@@ -18,9 +18,6 @@ L = importlib.import_module("moonbit-flate_amd._lib").load()
 L.flate_hip_debug_lz_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
 buf = np.zeros((n, 8), dtype=np.uint64)
 k = L.flate_hip_debug_lz_stamps(eng._ctx, buf.ctypes.data, n)
-b = buf[:k].astype(np.float64)
-names = ["dup+issue", "load_wait", "events", "commit", "batches", "matches", "general_cycles", "general_events"]
-m = b.mean(axis=0)
-print({names[i]: round(m[i], 1) for i in range(8)})
-nb = m[4]
-print("per batch (s_memtime ticks):", {names[i]: round(m[i] / nb, 1) for i in range(4)}, "events/batch", m[5] / nb)
+m = buf[:k].astype(np.float64).mean(axis=0)
+names = ["hist_walk", "build_lit", "build_off", "header", "emit_header", "emit_walk", "total", "-"]
+print({names[i]: round(m[i]) for i in range(7)})
