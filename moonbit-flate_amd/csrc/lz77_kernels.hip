@@ -187,6 +187,21 @@ FLATE_D uint64_t lanes_below(int l) { return l >= 64 ? ~0ull : ((1ull << l) - 1u
 FLATE_D uint64_t lanes_upto(int l) { return l >= 63 ? ~0ull : ((1ull << (l + 1)) - 1ull); }
 FLATE_D int ffs64(uint64_t m) { return m ? __builtin_ctzll(m) : 64; }
 
+// wave-wide OR of a 32-bit value (DPP row shifts / broadcasts, no LDS traffic)
+template <int CTRL, int ROW_MASK>
+FLATE_D uint32_t dpp_or(uint32_t v) {
+  return v | (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+FLATE_D uint32_t wave_or(uint32_t v) {
+  v = dpp_or<0x111, 0xf>(v);
+  v = dpp_or<0x112, 0xf>(v);
+  v = dpp_or<0x114, 0xf>(v);
+  v = dpp_or<0x118, 0xf>(v);
+  v = dpp_or<0x142, 0xa>(v);
+  v = dpp_or<0x143, 0xc>(v);
+  return rdlane(v, 63);
+}
+
 FLATE_D uint4 ld128(const uint8_t *p) {
   uint4 v;
   __builtin_memcpy(&v, p, 16);  // one unaligned global_load_dwordx4
@@ -311,7 +326,10 @@ __global__ __launch_bounds__(64) void lz77_wave_kernel(LzParams P) {
         const int tot_self = cross ? 4 : mlen;                   // 16 => needs extension (slow)
         uint32_t rec_tok = kMatchType | ((uint32_t)(tot_self - 3) << kLengthShift) | (A1 - old - 1);
         // speculative evaluation of the event that would start with s-1 == my lane
-        uint32_t ev;       // [6:0] match lane, [15:8] total length, bit16 slow, bit17 chunk ends
+        // ev: [6:0] match lane fv, [15:8] total length, bit16 general path needed, bit17 the
+        // match ends the chunk, bit18 stop chasing (chunk end or next start lane > kDenseKeep),
+        // [31:24] lane of the next event start (s-1 of the next event)
+        uint32_t ev;
         uint64_t insm;     // lanes inserted by that event
         {
           const int bsh = lane + 2;
@@ -324,31 +342,66 @@ __global__ __launch_bounds__(64) void lz77_wave_kernel(LzParams P) {
           const int tf = __shfl(tot_self, fv & 63);
           const bool slow = !(fv < fd) || tf >= 16;
           const bool ends = B + fv + tf >= s_limit;
-          ev = (uint32_t)(fv & 127) | ((uint32_t)tf << 8) | (slow ? 1u << 16 : 0u) | (ends ? 1u << 17 : 0u);
+          const int nxt = fv + tf - 1;
+          ev = (uint32_t)(fv & 127) | ((uint32_t)tf << 8) | (slow ? 1u << 16 : 0u) |
+               (ends ? 1u << 17 : 0u) | ((ends || nxt > kDenseKeep) ? 1u << 18 : 0u) |
+               ((uint32_t)(nxt & 255) << 24);
           insm = (R & lanes_upto(fv & 63)) | (E1 & (1ull << lane));
         }
         STAMP(t2);
 
-        uint64_t INS = 0, M = 0, MF = 0;  // inserted lanes, match lanes, match lanes of fast events
+        // Lanes inserted by the fast events whose start lanes are in `vis`: lane L belongs to the
+        // event starting at the last visited lane j <= L and was inserted iff it is on that
+        // event's probe schedule (j, j+1, then j+2+{0..31, 32,34,..}) and not past its match lane.
+        auto fast_inserts = [&](uint64_t vis) -> uint64_t {
+          const uint64_t below_me = vis & lanes_upto(lane);
+          const int j = below_me ? 63 - __builtin_clzll(below_me) : 0;
+          const int fvj = (int)(__shfl(ev, j) & 127u);
+          const int d = lane - j, o = d - 2;
+          const bool sched = (d <= 1 || o < 32) ? e1 : (((o & 1) == 0) ? e2 : false);
+          return __ballot(below_me != 0 && sched && lane <= fvj);
+        };
+        uint64_t INS = 0, M = 0, MF = 0;  // inserted lanes (general events), match lanes, fast match lanes
+        uint64_t VISall = 0;              // start lanes of the fast events chased so far
         int a = 0;
         for (;;) {  // events inside this batch
-          const uint32_t x = rdlane(ev, a);
-          if (!(x & (1u << 16))) {
-            // fast event: first valid probe lane has a private slot and a < 16-byte match
-            const int fv = (int)(x & 127u), tf = (int)((x >> 8) & 255u);
-            INS |= (uint64_t)rdlane((uint32_t)insm, a) | ((uint64_t)rdlane((uint32_t)(insm >> 32), a) << 32);
-            M |= 1ull << fv;
-            MF |= 1ull << fv;
-            s = B + fv + tf;
-            if (x & (1u << 17)) {
-              done = true;
-              break;
-            }
-            a = fv + tf - 1;
-            if (a > kDenseKeep) break;
-            continue;
+          // Chase the fast events: x = ev[a]; visit a; a = next[a]; until an event needs the
+          // general path or asks to stop.  Hand-written: the whole step is 9 scalar
+          // instructions (the compiler's version of this loop cost ~290 cycles per match).
+          uint32_t x, tmp;
+          uint64_t VIS = 0, MFl = 0;
+          int a_s = __builtin_amdgcn_readfirstlane(a);
+          STAMP(tc0);
+          asm volatile(
+              "1:\n\t"
+              "s_nop 1\n\t"
+              "v_readlane_b32 %[x], %[ev], %[a]\n\t"
+              "s_nop 3\n\t"
+              "s_bitcmp1_b32 %[x], 16\n\t"
+              "s_cbranch_scc1 2f\n\t"
+              "s_bitset1_b64 %[vis], %[a]\n\t"
+              "s_and_b32 %[t], %[x], 0x7f\n\t"
+              "s_bitset1_b64 %[mf], %[t]\n\t"
+              "s_lshr_b32 %[a], %[x], 24\n\t"
+              "s_bitcmp1_b32 %[x], 18\n\t"
+              "s_cbranch_scc0 1b\n\t"
+              "2:\n\t"
+              : [x] "=&s"(x), [a] "+s"(a_s), [vis] "+s"(VIS), [mf] "+s"(MFl), [t] "=&s"(tmp)
+              : [ev] "v"(ev)
+              : "scc");
+          a = a_s;
+          MF |= MFl;
+          STAMP(tc1);
+          STAMP_ADD(st_sparse, tc1, tc0);
+          VISall |= VIS;
+          s = B + a + 1;
+          if (!(x & (1u << 16))) {  // stopped after a fast event
+            if (x & (1u << 17)) done = true;
+            break;
           }
           // ---- general event (shared slots, long matches, end of scan) ----
+          STAMP(tg0);
+          const uint64_t FINS = fast_inserts(VISall);
           const uint64_t a_ins = E1 & (1ull << a);
           const int b = a + 2;
           const uint64_t full = 0x55555555ffffffffull << b;  // scan probe lanes (steps 1 then 2)
@@ -376,7 +429,7 @@ __global__ __launch_bounds__(64) void lz77_wave_kernel(LzParams P) {
             // latest position this batch has already inserted into that slot
             T |= rem & lanes_below(fd);
             const uint32_t hfd = rdlane(h, fd);
-            const uint64_t G = __ballot(e1 && h == hfd) & (INS | T | a_ins) & lanes_below(fd);
+            const uint64_t G = __ballot(e1 && h == hfd) & (INS | FINS | T | a_ins) & lanes_below(fd);
             bool v;
             uint32_t cnd;
             int ml;
@@ -429,6 +482,8 @@ __global__ __launch_bounds__(64) void lz77_wave_kernel(LzParams P) {
             acc_len += (uint32_t)total;
           }
           s = pf + total;
+          STAMP(tg1);
+          STAMP_ADD(st_ext, tg1, tg0);
           if (s >= s_limit) {
             done = true;
             break;
@@ -436,6 +491,8 @@ __global__ __launch_bounds__(64) void lz77_wave_kernel(LzParams P) {
           a = s - 1 - B;
           if (a > kDenseKeep) break;
         }
+        M |= MF;
+        INS |= fast_inserts(VISall);
         STAMP(t3);
         // match records of this batch, in position order, one coalesced store
         if ((MF >> lane) & 1) acc_len += (uint32_t)tot_self;

@@ -19,7 +19,7 @@ L.flate_hip_debug_lz_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
 buf = np.zeros((n, 8), dtype=np.uint64)
 k = L.flate_hip_debug_lz_stamps(eng._ctx, buf.ctypes.data, n)
 b = buf[:k].astype(np.float64)
-names = ["dup+issue", "load_wait", "events", "commit", "batches", "matches", "general_cycles", "general_events"]
+names = ["dup+issue", "load_wait", "events", "commit", "batches", "matches", "general_cycles", "chase_cycles"]
 m = b.mean(axis=0)
 print({names[i]: round(m[i], 1) for i in range(8)})
 nb = m[4]
