@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-streams", type=int, default=4096)
     ap.add_argument("--verify", type=int, default=64, help="streams checked against the oracle")
+    ap.add_argument("--mode", default="deflate", choices=["deflate", "inflate"],
+                    help="inflate = BASELINE.json configs[4]: decode the compressed streams (stream index supplied)")
     args = ap.parse_args()
 
     import torch
@@ -73,6 +75,9 @@ def main():
     eng.use_stream(torch.cuda.current_stream().cuda_stream)
     eng.set_profiling(True)
     out = torch.empty(in_bytes + (in_bytes >> 3) + 4096, dtype=torch.uint8, device=dev)
+
+    if args.mode == "inflate":
+        return bench_inflate(args, flate, eng, d_in, in_off, n, blen, world, rank, dev, dist)
 
     gather = (world > 1) and not args.no_gather
     shard = importlib.import_module("moonbit-flate_amd.shard")
@@ -168,6 +173,56 @@ def main():
             "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+def bench_inflate(args, flate, eng, d_in, in_off, n, blen, world, rank, dev, dist):
+    """Config 5: inflate-only.  Streams compressed once (untimed) by the encoder; one step = one
+    inflate_batch over all of them; value = GiB/s of decompressed output."""
+    import torch
+    comp, coff = eng.deflate_batch(d_in, in_off)
+    sizes = [blen] * n
+    out = torch.empty(n * blen, dtype=torch.uint8, device=dev)
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.inflate_batch(comp, coff, sizes, out=out)
+    ms = 0.0
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        _, _, olen, status, _ = eng.inflate_batch(comp, coff, sizes, out=out)
+        ms += eng.last_timing()["inflate"]
+    sync_all()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ok = bool((status == 0).all()) and bool(torch.equal(out, d_in))  # round-trip property, full size
+    if rank == 0:
+        clen = int(coff[-1])
+        k_ms = ms / args.steps
+        achieved = (n * blen + clen) / (k_ms * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": "GiB/s decompressed output (inflate), 64 KiB streams", "unit": "GiB/s",
+            "value": round(world * n * blen * args.steps / dt / 2**30, 3), "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": "inflate %d x %d B streams per GPU, S-%s, output == input: %s"
+                                   % (n, blen, args.kind, ok), "stage_ms": {"inflate": round(k_ms, 3)}},
+            "roofline": {"bound": "hbm", "kernel": "inflate_kernel", "achieved": round(achieved, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": None},
+            "cpu_baseline": None}))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -455,11 +455,58 @@ int flate_hip_debug_lz_stamps(flate_hip_ctx *c, uint64_t *out, uint32_t max_chun
 int flate_hip_inflate_batch(flate_hip_ctx *c, const uint8_t *in, const uint64_t *in_off, uint32_t n,
                             uint8_t *out, const uint64_t *out_off, uint64_t *out_len,
                             int32_t *status, int64_t *err_off, uint32_t flags) {
-  (void)in; (void)in_off; (void)n; (void)out; (void)out_off; (void)out_len; (void)status;
-  (void)err_off; (void)flags;
-  if (!c) return FLATE_HIP_E_INVALID;
-  c->hip_err = "inflate kernel not built yet";
-  return FLATE_HIP_E_INVALID;
+  if (!c || !in_off || !out_off || !out_len || !status || !err_off || (n && (!in || !out)))
+    return FLATE_HIP_E_INVALID;
+  c->hip_err.clear();
+  if (n == 0) return FLATE_HIP_OK;
+  for (uint32_t i = 0; i < n; ++i)
+    if (in_off[i + 1] < in_off[i] || out_off[i + 1] < out_off[i]) return FLATE_HIP_E_INVALID;
+  for (uint32_t i = 0; i < n; ++i)
+    if (in_off[i + 1] - in_off[i] >= 0x7ffe0000ull) return FLATE_HIP_E_TOO_LARGE;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const bool dev = (flags & FLATE_HIP_DEVICE_PTRS) != 0;
+  int rc;
+  const uint8_t *d_in = in;
+  uint8_t *d_out = out;
+  if (!dev) {
+    if ((rc = ensure(c, c->d_in, in_off[n] + 16))) return rc;
+    if ((rc = ensure(c, c->d_out, out_off[n] + 16))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->d_in.p, in, in_off[n], hipMemcpyHostToDevice, c->stream));
+    d_in = (const uint8_t *)c->d_in.p;
+    d_out = (uint8_t *)c->d_out.p;
+  }
+  if ((rc = ensure(c, c->d_in_off, ((size_t)n + 1) * 8))) return rc;
+  if ((rc = ensure(c, c->d_slot_off, ((size_t)n + 1) * 8))) return rc;
+  if ((rc = ensure(c, c->d_out_len, (size_t)n * 8 + 8))) return rc;
+  if ((rc = ensure(c, c->d_istatus, (size_t)n * 4 + 4))) return rc;
+  if ((rc = ensure(c, c->d_ierr, (size_t)n * 8 + 8))) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->d_in_off.p, in_off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_slot_off.p, out_off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  InfParams I;
+  I.in = d_in;
+  I.in_off = (const uint64_t *)c->d_in_off.p;
+  I.out = d_out;
+  I.out_off = (const uint64_t *)c->d_slot_off.p;
+  I.out_len = (uint64_t *)c->d_out_len.p;
+  I.status = (int32_t *)c->d_istatus.p;
+  I.err_off = (int64_t *)c->d_ierr.p;
+  I.n_streams = n;
+  {
+    StageTimer t(c, FLATE_HIP_STAGE_INFLATE);
+    hipLaunchKernelGGL(inflate_kernel, dim3(n), dim3(64), 0, c->stream, I);
+  }
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(out_len, c->d_out_len.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(status, c->d_istatus.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(err_off, c->d_ierr.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+  if (!dev)
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_out.p, out_off[n], hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const bool used[FLATE_HIP_STAGE_COUNT] = {false, false, false, true};
+  if ((rc = collect_timing(c, used))) return rc;
+  for (uint32_t i = 0; i < n; ++i)
+    if (status[i]) return status[i];
+  return FLATE_HIP_OK;
 }
 
 }  // extern "C"

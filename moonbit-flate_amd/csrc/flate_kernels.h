@@ -49,11 +49,23 @@ struct CompactParams {
   int *status;  // set to FLATE_HIP_E_OUT_TOO_SMALL if the total exceeds out_cap
 };
 
+struct InfParams {
+  const uint8_t *in;
+  const uint64_t *in_off;   // n_streams + 1
+  uint8_t *out;
+  const uint64_t *out_off;  // n_streams + 1: slot of every stream's output (capacity)
+  uint64_t *out_len;
+  int32_t *status;
+  int64_t *err_off;
+  uint32_t n_streams;
+};
+
 __global__ void lz77_serial_kernel(LzParams P);
 template <typename E>
 __global__ void lz77_wave_kernel(LzParams P);
 __global__ void huff_pack_kernel(HuffParams P);
 __global__ void scan_sizes_kernel(CompactParams P);
 __global__ void compact_kernel(CompactParams P);
+__global__ void inflate_kernel(InfParams P);
 
 }  // namespace flate

@@ -1,0 +1,538 @@
+// inflate_kernels.hip -- batch inflater for gfx950: one wavefront per DEFLATE stream.
+//
+// Replaces, for N independent streams, the reference decoder:
+//   Decompressor::next_block / read_huffman / read_literal / huff_sym / data_block
+//                                   inflate.mbt:345-379, 429-548, 565-684, 803-854, 708-766
+//   HuffmanDecoder::initialize      inflate.mbt:100-223
+//   DictDecoder::write_copy         dict-decoder.mbt:114-185  (the history IS the output buffer)
+//
+// Decoding one stream is serial (every code starts where the previous one ended), so lane 0
+// walks the bit stream; all 64 lanes build the decode tables (one symbol per lane) and perform
+// the LZ77 / stored-block copies 64 bytes at a time.  Parallelism comes from the batch:
+// thousands of streams, up to 8 waves per SIMD.
+//
+// Tables are not the reference's chunk/link tables: a 9-bit primary table (symbol, length) plus
+// canonical first-code/count arrays for the (rare) longer codes -- same symbols, same accept /
+// reject decisions.  Error reporting follows the reference exactly: the byte offset in
+// corrupt_input_error (inflate.mbt:38) is the number of input bytes the byte-at-a-time reader
+// (more_bits :789, huff_sym :818-831) has consumed, which is a function of the bits requested so
+// far: roffset = max(roffset, ceil((consumed_bits + requested) / 8)).
+#include "flate_kernels.h"
+
+namespace flate {
+
+namespace {
+
+constexpr int kPrimBits = 9;  // huffman_chunk_bits, inflate.mbt:69
+constexpr int kPrimSize = 1 << kPrimBits;
+constexpr int kMaxLit = 286, kMaxDist = 30, kNumCodes = 19;
+constexpr uint16_t kLongCode = 0x000f;
+
+constexpr int E_OUT_SMALL = -2, E_CORRUPT = -4, E_EOF = -7;
+
+
+// one Huffman decoder (inflate.mbt:81-86), canonical form
+struct Dec {
+  uint16_t prim[kPrimSize];  // (sym << 4) | len for len <= 9; kLongCode = longer code; 0 = invalid
+  uint16_t sorted[288];      // symbols ordered by (len, symbol)
+  uint32_t count[16];        // codes per length
+  uint32_t first[16];        // first canonical code of each length
+  uint32_t offs[16];         // index into sorted of the first symbol of each length
+  int32_t min;               // minimum code length (h.min), 0 = empty tree
+  int32_t max;
+  int32_t ok;
+};
+
+__constant__ uint8_t kCodeOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+FLATE_D uint32_t ld32g(const uint8_t *p) {
+  uint32_t v;
+  __builtin_memcpy(&v, p, 4);
+  return v;
+}
+
+// HuffmanDecoder::initialize (inflate.mbt:100-223) over lens[0..n), n <= 288.  All lanes.
+// d.ok = 0 for an over- or under-subscribed code (:161).
+__device__ __noinline__ void dec_init(Dec &d, const uint8_t *lens, int n, int lane) {
+  for (int i = lane; i < kPrimSize; i += 64) d.prim[i] = 0;
+  if (lane < 16) d.count[lane] = 0;
+  __syncthreads();
+  for (int i = lane; i < n; i += 64)
+    if (lens[i]) atomicAdd(&d.count[lens[i]], 1u);
+  __syncthreads();
+  if (lane == 0) {
+    int mn = 0, mx = 0;
+    for (int l = 1; l < 16; ++l)
+      if (d.count[l]) {
+        if (!mn) mn = l;
+        mx = l;
+      }
+    d.min = mn;
+    d.max = mx;
+    d.ok = 1;
+    uint32_t code = 0, off = 0;
+    for (int l = 0; l < 16; ++l) {
+      d.first[l] = 0;
+      d.offs[l] = off;
+    }
+    for (int l = mn; l <= mx && mx; ++l) {  // :148-154
+      code <<= 1;
+      d.first[l] = code;
+      d.offs[l] = off;
+      code += d.count[l];
+      off += d.count[l];
+    }
+    if (mx && code != (1u << mx) && !(code == 1 && mx == 1)) d.ok = 0;  // :161
+  }
+  __syncthreads();
+  if (d.max == 0 || !d.ok) return;  // empty tree is valid (:143-145)
+  // canonical rank of every symbol inside its length, in symbol order (running counts are
+  // wave-uniform, so every lane keeps its own copy in registers)
+  uint32_t run[16];
+#pragma unroll
+  for (int l = 0; l < 16; ++l) run[l] = 0;
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    const uint32_t L = i < n ? lens[i] : 0u;
+    uint32_t rank = 0;
+#pragma unroll
+    for (int l = 1; l < 16; ++l) {
+      const uint64_t m = __ballot(L == (uint32_t)l);
+      if (L == (uint32_t)l) rank = run[l] + __popcll(m & ((1ull << lane) - 1));
+      run[l] += __popcll(m);
+    }
+    if (L) {
+      const uint32_t code = d.first[L] + rank;
+      d.sorted[d.offs[L] + rank] = (uint16_t)i;
+      if (L <= (uint32_t)kPrimBits) {
+        const uint32_t rev = __brev(code) >> (32 - L);
+        const uint16_t e = (uint16_t)((i << 4) | L);
+        for (uint32_t k = rev; k < (uint32_t)kPrimSize; k += 1u << L) d.prim[k] = e;
+      } else {
+        const uint32_t top = code >> (L - kPrimBits);
+        d.prim[__brev(top) >> (32 - kPrimBits)] = kLongCode;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// Wave-uniform bit reader over the LDS stage of the compressed input.  Every value below is
+// the same in all 64 lanes and lives in SGPRs (LDS look-ups go through v_readfirstlane), so the
+// serial symbol loop runs on the scalar unit; the vector lanes are used for the copies.
+constexpr int kStage = 2048;      // bytes of compressed input staged in LDS
+constexpr int kStageMargin = 64;  // restage when fewer bytes than this remain staged
+constexpr int kWin = 32768;       // history window (max_match_offset, inflate.mbt:330)
+constexpr int kFlushAt = 8192;    // flush the window to HBM when this much output is pending
+
+FLATE_D uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+struct InfShared {
+  Dec lit, dist;
+  uint8_t lens[kMaxLit + kMaxDist + 2 + 288];
+  uint32_t stage[kStage / 4];
+  uint8_t win[kWin];  // DictDecoder.hist (dict-decoder.mbt:29-35): the last 32 KiB of output
+};
+
+struct Bits {      // 32-bit offsets: the API rejects streams >= 2 GiB
+  uint32_t in_len;
+  uint32_t roff;   // bytes the reference's reader has consumed (roffset, inflate.mbt:260)
+  uint32_t ipos;   // next byte of the stream to load into buf
+  uint32_t sbase;  // stream offset of stage[0]
+  uint64_t buf;    // physical look-ahead, LSB first
+  int32_t cnt;     // valid bits in buf
+  int32_t avail;   // bits the reference's reader holds: 8 * roff - consumed bits
+};
+
+FLATE_D void bits_refill(Bits &b, const uint32_t *stage) {
+  while (b.cnt <= 32) {
+    const uint32_t idx = (b.ipos - b.sbase) >> 2;
+    const uint32_t w = idx < (uint32_t)(kStage / 4) ? uni(stage[idx]) : 0u;  // past the stage: zeros
+    b.buf |= (uint64_t)w << b.cnt;
+    b.cnt += 32;
+    b.ipos += 4;
+  }
+}
+// the reader asks for n more bits: false = the input ends first
+FLATE_D bool bits_need(Bits &b, int n) {
+  if (n > b.avail) {
+    const int bytes = (n - b.avail + 7) >> 3;
+    if (b.roff + (uint32_t)bytes > b.in_len) {
+      b.roff = b.in_len;
+      return false;
+    }
+    b.roff += (uint32_t)bytes;
+    b.avail += 8 * bytes;
+  }
+  return true;
+}
+FLATE_D uint32_t bits_peek(const Bits &b, uint32_t n) { return (uint32_t)b.buf & ((1u << n) - 1u); }
+FLATE_D void bits_drop(Bits &b, int n, const uint32_t *stage) {
+  b.buf >>= n;
+  b.cnt -= n;
+  b.avail -= n;
+  if (b.cnt <= 32) bits_refill(b, stage);
+}
+
+// huff_sym (inflate.mbt:803-854).  Returns the symbol, or -1 with *err set.
+FLATE_D int huff_sym(Bits &b, const Dec &d, int dmin, int dmax, const uint32_t *stage, int *err) {
+  if (!bits_need(b, dmin)) {
+    *err = E_EOF;
+    return -1;
+  }
+  const uint32_t e = uni(d.prim[(uint32_t)b.buf & (kPrimSize - 1)]);
+  if (e == 0) {
+    *err = E_CORRUPT;
+    return -1;
+  }
+  if (e != kLongCode) {
+    const int len = (int)(e & 15u);
+    if (!bits_need(b, len)) {
+      *err = E_EOF;
+      return -1;
+    }
+    bits_drop(b, len, stage);
+    return (int)(e >> 4);
+  }
+  uint32_t code = __brev((uint32_t)b.buf & (kPrimSize - 1)) >> (32 - kPrimBits);
+  for (int L = kPrimBits + 1; L <= dmax; ++L) {
+    code = (code << 1) | ((uint32_t)(b.buf >> (L - 1)) & 1u);
+    const uint32_t idx = code - uni(d.first[L]);
+    if (idx < uni(d.count[L])) {
+      if (!bits_need(b, L)) {
+        *err = E_EOF;
+        return -1;
+      }
+      bits_drop(b, L, stage);
+      return (int)uni(d.sorted[uni(d.offs[L]) + idx]);
+    }
+  }
+  *err = E_CORRUPT;
+  return -1;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(64) void inflate_kernel(InfParams P) {
+  __shared__ InfShared sh;
+  const int lane = threadIdx.x;
+  const uint32_t sid = blockIdx.x;
+  if (sid >= P.n_streams) return;
+  uint8_t *out = P.out + P.out_off[sid];
+  const uint64_t cap64 = P.out_off[sid + 1] - P.out_off[sid];
+  const uint32_t out_cap = cap64 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)cap64;
+  const uint8_t *in = P.in + P.in_off[sid];
+  const uint32_t in_len = (uint32_t)(P.in_off[sid + 1] - P.in_off[sid]);
+
+  Bits b;
+  b.in_len = in_len;
+  b.roff = 0;
+  b.ipos = 0;
+  b.sbase = 0;
+  b.buf = 0;
+  b.cnt = 0;
+  b.avail = 0;
+  uint32_t opos = 0;  // bytes produced
+  uint32_t fpos = 0;  // bytes already flushed to HBM
+  int err = 0;
+  bool final_block = false;
+
+  // (re)load the LDS stage of the compressed input at b.ipos
+  auto restage = [&]() {
+    __syncthreads();
+    const uint32_t base = b.ipos;
+    for (int k = lane; k < kStage / 4; k += 64) {
+      const uint32_t p = base + 4u * k;
+      uint32_t w = 0;
+      if (p + 4 <= in_len) {
+        w = ld32g(in + p);
+      } else {
+        for (uint32_t q = p; q < in_len; ++q) w |= (uint32_t)in[q] << (8 * (q - p));
+      }
+      sh.stage[k] = w;
+    }
+    b.sbase = base;
+    __syncthreads();
+    bits_refill(b, sh.stage);
+  };
+  auto stage_low = [&]() { return b.ipos + kStageMargin > b.sbase + kStage && b.sbase + kStage < in_len; };
+  // read_flush (dict-decoder.mbt:200-209): window -> HBM, coalesced
+  auto flush = [&]() {
+    __syncthreads();
+    for (uint32_t i = fpos + lane; i < opos; i += 64) out[i] = sh.win[i & (kWin - 1)];
+    fpos = opos;
+  };
+
+  // Re-assert wave-uniformity of the decoder state (no-ops at run time: every lane already holds
+  // the same values) so that the symbol loop is compiled for the scalar unit.
+  auto pin = [&]() {
+    b.roff = uni(b.roff);
+    b.ipos = uni(b.ipos);
+    b.sbase = uni(b.sbase);
+    b.buf = ((uint64_t)uni((uint32_t)(b.buf >> 32)) << 32) | uni((uint32_t)b.buf);
+    b.cnt = (int)uni((uint32_t)b.cnt);
+    b.avail = (int)uni((uint32_t)b.avail);
+    opos = uni(opos);
+    fpos = uni(fpos);
+    err = (int)uni((uint32_t)err);
+  };
+
+  restage();
+  while (!final_block && !err) {  // next_block (inflate.mbt:345-379)
+    pin();
+    if (stage_low()) restage();
+    if (!bits_need(b, 3)) {
+      err = E_EOF;
+      break;
+    }
+    const uint32_t h = bits_peek(b, 3);
+    final_block = h & 1;
+    const uint32_t typ = h >> 1;
+    bits_drop(b, 3, sh.stage);
+    if (typ == 3) {
+      err = E_CORRUPT;  // reserved (:375-377)
+      break;
+    }
+    if (typ == 0) {  // data_block (:708-766): discard the partial byte, LEN, ~LEN, raw bytes
+      const uint32_t p = b.roff;
+      if (in_len - p < 4) {
+        b.roff = in_len;
+        err = E_EOF;
+        break;
+      }
+      b.roff = p + 4;
+      const uint32_t n = uni((uint32_t)in[p] | ((uint32_t)in[p + 1] << 8));
+      const uint32_t nn = uni((uint32_t)in[p + 2] | ((uint32_t)in[p + 3] << 8));
+      if ((nn & 0xffffu) != ((~n) & 0xffffu)) {
+        err = E_CORRUPT;
+        break;
+      }
+      flush();
+      const uint32_t ip = b.roff, avail = in_len - ip;
+      const uint32_t cnt = avail < n ? avail : n;
+      if (cnt > out_cap - opos) {
+        err = E_OUT_SMALL;
+        break;
+      }
+      for (uint32_t i = lane; i < cnt; i += 64) {
+        const uint8_t v = in[ip + i];
+        out[opos + i] = v;
+        sh.win[(opos + i) & (kWin - 1)] = v;
+      }
+      opos += cnt;
+      fpos = opos;
+      b.roff += cnt;
+      if (cnt < n) {
+        err = E_EOF;
+        break;
+      }
+      b.ipos = b.roff;  // the bit reader restarts at the byte after the block
+      b.buf = 0;
+      b.cnt = 0;
+      b.avail = 0;
+      restage();
+      continue;
+    }
+    int lit_min, lit_max, dist_min, dist_max;
+    if (typ == 1) {  // fixed_huffman_decoder (:886-939); distances are 5-bit codes
+      __syncthreads();
+      uint8_t *fl = sh.lens + 32;
+      for (int i = lane; i < 288; i += 64) fl[i] = i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8));
+      if (lane < 32) fl[288 + lane] = 5;
+      __syncthreads();
+      dec_init(sh.lit, fl, 288, lane);
+      dec_init(sh.dist, fl + 288, 32, lane);
+    } else {  // read_huffman (:429-548)
+      if (!bits_need(b, 14)) {
+        err = E_EOF;
+        break;
+      }
+      const uint32_t v = bits_peek(b, 14);
+      const int nlit = (int)(v & 31u) + 257, ndist = (int)((v >> 5) & 31u) + 1;
+      const int nclen = (int)((v >> 10) & 15u) + 4;
+      if (nlit > kMaxLit || ndist > kMaxDist) {
+        err = E_CORRUPT;
+        break;
+      }
+      bits_drop(b, 14, sh.stage);
+      __syncthreads();
+      if (lane < kNumCodes) sh.lens[lane] = 0;
+      __syncthreads();
+      for (int i = 0; i < nclen && !err; ++i) {
+        if (!bits_need(b, 3)) {
+          err = E_EOF;
+          break;
+        }
+        if (lane == 0) sh.lens[kCodeOrder[i]] = (uint8_t)bits_peek(b, 3);
+        bits_drop(b, 3, sh.stage);
+      }
+      if (err) break;
+      __syncthreads();
+      dec_init(sh.dist, sh.lens, kNumCodes, lane);  // code-length code
+      if (!uni((uint32_t)sh.dist.ok)) {
+        err = E_CORRUPT;
+        break;
+      }
+      const int cmin = (int)uni((uint32_t)sh.dist.min), cmax = (int)uni((uint32_t)sh.dist.max);
+      uint8_t *cl = sh.lens + 32;
+      const int total = nlit + ndist;
+      int i = 0;
+      while (i < total) {  // :471-530
+        pin();
+        i = (int)uni((uint32_t)i);
+        if (stage_low()) restage();
+        const int x = huff_sym(b, sh.dist, cmin, cmax, sh.stage, &err);
+        if (x < 0) break;
+        if (x < 16) {
+          if (lane == 0) cl[i] = (uint8_t)x;
+          ++i;
+          continue;
+        }
+        int rep, nb;
+        uint32_t fill = 0;
+        if (x == 16) {
+          rep = 3;
+          nb = 2;
+          if (i == 0) {
+            err = E_CORRUPT;
+            break;
+          }
+          __syncthreads();
+          fill = uni(cl[i - 1]);
+        } else if (x == 17) {
+          rep = 3;
+          nb = 3;
+        } else {
+          rep = 11;
+          nb = 7;
+        }
+        if (!bits_need(b, nb)) {
+          err = E_EOF;
+          break;
+        }
+        rep += (int)bits_peek(b, (uint32_t)nb);
+        bits_drop(b, nb, sh.stage);
+        if (i + rep > total) {
+          err = E_CORRUPT;
+          break;
+        }
+        if (lane < rep) cl[i + lane] = (uint8_t)fill;
+        if (lane + 64 < rep) cl[i + lane + 64] = (uint8_t)fill;
+        if (lane + 128 < rep) cl[i + lane + 128] = (uint8_t)fill;
+        i += rep;
+      }
+      if (err) break;
+      __syncthreads();
+      dec_init(sh.lit, cl, nlit, lane);
+      dec_init(sh.dist, cl + nlit, ndist, lane);
+      if (!uni((uint32_t)sh.lit.ok) || !uni((uint32_t)sh.dist.ok)) {
+        err = E_CORRUPT;
+        break;
+      }
+    }
+    lit_min = (int)uni((uint32_t)sh.lit.min);
+    lit_max = (int)uni((uint32_t)sh.lit.max);
+    dist_min = (int)uni((uint32_t)sh.dist.min);
+    dist_max = (int)uni((uint32_t)sh.dist.max);
+    if (typ == 2) {  // read at least the end-of-block code's length (:542-544)
+      const int eob = (int)uni(sh.lens[32 + 256]);
+      if (lit_min < eob) lit_min = eob;
+    }
+
+    for (;;) {  // read_literal (:565-684)
+      pin();
+      if (stage_low()) restage();
+      if (opos - fpos >= (uint32_t)kFlushAt) flush();
+      const int v = huff_sym(b, sh.lit, lit_min, lit_max, sh.stage, &err);
+      if (v < 0) break;
+      if (v < 256) {
+        if (opos >= out_cap) {
+          err = E_OUT_SMALL;
+          break;
+        }
+        if (lane == 0) sh.win[opos & (kWin - 1)] = (uint8_t)v;  // DictDecoder::write_byte
+        ++opos;
+        continue;
+      }
+      if (v == 256) break;  // finish_block
+      int length, n;
+      if (v < 265) {
+        length = v - (257 - 3);
+        n = 0;
+      } else if (v < 269) {
+        length = v * 2 - (265 * 2 - 11);
+        n = 1;
+      } else if (v < 273) {
+        length = v * 4 - (269 * 4 - 19);
+        n = 2;
+      } else if (v < 277) {
+        length = v * 8 - (273 * 8 - 35);
+        n = 3;
+      } else if (v < 281) {
+        length = v * 16 - (277 * 16 - 67);
+        n = 4;
+      } else if (v < 285) {
+        length = v * 32 - (281 * 32 - 131);
+        n = 5;
+      } else if (v < kMaxLit) {
+        length = 258;
+        n = 0;
+      } else {
+        err = E_CORRUPT;
+        break;
+      }
+      if (n > 0) {
+        if (!bits_need(b, n)) {
+          err = E_EOF;
+          break;
+        }
+        length += (int)bits_peek(b, (uint32_t)n);
+        bits_drop(b, n, sh.stage);
+      }
+      int dist = huff_sym(b, sh.dist, dist_min, dist_max, sh.stage, &err);
+      if (dist < 0) break;
+      if (dist < 4) {
+        dist += 1;
+      } else if (dist < kMaxDist) {
+        const int nb = (dist - 2) >> 1;
+        int extra = (dist & 1) << nb;
+        if (!bits_need(b, nb)) {
+          err = E_EOF;
+          break;
+        }
+        extra |= (int)bits_peek(b, (uint32_t)nb);
+        bits_drop(b, nb, sh.stage);
+        dist = (1 << (nb + 1)) + 1 + extra;
+      } else {
+        err = E_CORRUPT;
+        break;
+      }
+      const uint32_t hist = opos < (uint32_t)kWin ? opos : (uint32_t)kWin;  // hist_size
+      if ((uint32_t)dist > hist) {
+        err = E_CORRUPT;
+        break;
+      }
+      if ((uint32_t)length > out_cap - opos) {
+        err = E_OUT_SMALL;
+        break;
+      }
+      // copy_history (:689) / write_copy (dict-decoder.mbt:114-154); overlap = periodic extension
+      __syncthreads();
+      const uint32_t op = opos;
+      for (int i = lane; i < length; i += 64) {
+        const int o = dist >= length ? i : i % dist;
+        sh.win[(op + (uint32_t)i) & (kWin - 1)] = sh.win[(op - (uint32_t)dist + (uint32_t)o) & (kWin - 1)];
+      }
+      __syncthreads();
+      opos += (uint32_t)length;
+    }
+  }
+  flush();
+  if (lane == 0) {
+    P.out_len[sid] = opos;
+    P.status[sid] = err;
+    P.err_off[sid] = err == E_CORRUPT ? (long long)b.roff : -1;
+  }
+}
+
+}  // namespace flate

@@ -1,0 +1,110 @@
+"""GPU parity tests of the batch inflater (inflate.mbt / dict-decoder.mbt) against the oracle."""
+import zlib
+
+import numpy as np
+import pytest
+
+from util import flate, make_streams
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    flate.build()
+    e = flate.FlateEngine(0)
+    yield e
+    e.close()
+
+
+def _pack(blobs):
+    lens = np.array([len(b) for b in blobs], dtype=np.uint64)
+    off = np.zeros(len(blobs) + 1, np.uint64)
+    np.cumsum(lens, out=off[1:])
+    data = np.frombuffer(b"".join(blobs) + b"\0" * 8, dtype=np.uint8).copy()
+    return data, off
+
+
+def test_inflate_round_trip_of_gpu_and_oracle_streams(eng, oracle):
+    specs = [("text", 65536), ("ramp", 65536), ("zero", 70000), ("rand", 65536), ("low", 131072),
+             ("period", 200000), ("runs", 65535), ("text", 0), ("text", 1), ("text", 16), ("text", 17),
+             ("text", 127), ("text", 128), ("text", 300), ("text", 262144)]
+    data, off = make_streams(specs)
+    comp, coff = eng.deflate_batch(data, off)
+    sizes = (off[1:] - off[:-1])
+    out, ooff, olen, status, err = eng.inflate_batch(comp, coff, sizes)
+    assert (status == 0).all() and (olen == sizes).all()
+    assert np.array_equal(out[:int(ooff[-1])], data[:int(off[-1])])
+    # identical behaviour to the oracle's decoder on the same bytes
+    for i, (kind, n) in enumerate(specs):
+        c = bytes(comp[int(coff[i]):int(coff[i + 1])])
+        assert oracle.inflate(c, n) == bytes(data[int(off[i]):int(off[i + 1])])
+
+
+def test_inflate_accepts_foreign_encoders(eng, oracle):
+    # stored / fixed / dynamic blocks, long codes, long distances, from zlib at several levels
+    rng = np.random.default_rng(5)
+    srcs = [b"the quick brown fox jumps over the lazy dog " * 2000, b"abc", b"",
+            bytes(rng.integers(0, 8, 120000, dtype=np.uint8)),
+            bytes(rng.integers(0, 256, 70000, dtype=np.uint8)),
+            bytes(flate.synth("text", 1, 300000)),
+            bytes(np.repeat(rng.integers(0, 256, 3000, dtype=np.uint8), rng.integers(1, 300, 3000)))]
+    blobs, want = [], []
+    for s in srcs:
+        for level in (0, 1, 6, 9):
+            co = zlib.compressobj(level, zlib.DEFLATED, -15)
+            blobs.append(co.compress(s) + co.flush())
+            want.append(s)
+        co = zlib.compressobj(6, zlib.DEFLATED, -15, 9, zlib.Z_FIXED)
+        blobs.append(co.compress(s) + co.flush())
+        want.append(s)
+    data, off = _pack(blobs)
+    sizes = [len(w) for w in want]
+    out, ooff, olen, status, err = eng.inflate_batch(data, off, sizes)
+    assert (status == 0).all()
+    for i, w in enumerate(want):
+        assert bytes(out[int(ooff[i]):int(ooff[i]) + int(olen[i])]) == w, i
+
+
+def test_inflate_errors_match_oracle(eng, oracle):
+    good = oracle.deflate(bytes(flate.synth("text", 1, 5000)))
+    rng = np.random.default_rng(9)
+    blobs = [bytes([0x07]), b"", good[:-3], good[:100], bytes([1, 5, 0, 0, 0]), bytes([0x03, 0x02, 0x00]),
+             bytes([0x05, 0xff, 0xff, 0xff]), bytes([0x04, 0x00])]
+    for _ in range(40):  # random corruptions of a valid stream
+        g = bytearray(good)
+        for k in rng.integers(0, len(g), int(rng.integers(1, 4))):
+            g[int(k)] ^= int(rng.integers(1, 256))
+        blobs.append(bytes(g))
+    for _ in range(20):
+        blobs.append(bytes(rng.integers(0, 256, int(rng.integers(1, 200)), dtype=np.uint8)))
+    data, off = _pack(blobs)
+    cap = 20000
+    out, ooff, olen, status, err = eng.inflate_batch(data, off, [cap] * len(blobs), check=False)
+    for i, bl in enumerate(blobs):
+        rc, res, used, eoff = oracle.inflate(bl, cap, full=True)
+        want_status = {0: 0, oracle.E_CORRUPT: -4, oracle.E_UNEXPECTED_EOF: -7,
+                       oracle.E_OUT_TOO_SMALL: -2}[rc]
+        assert int(status[i]) == want_status, (i, bl[:8].hex(), int(status[i]), rc)
+        assert int(err[i]) == eoff, (i, int(err[i]), eoff)
+        if rc == 0:
+            assert bytes(out[int(ooff[i]):int(ooff[i]) + int(olen[i])]) == res
+
+
+def test_inflate_output_too_small(eng, oracle):
+    good = oracle.deflate(bytes(flate.synth("text", 1, 5000)))
+    data, off = _pack([good])
+    out, ooff, olen, status, err = eng.inflate_batch(data, off, [100], check=False)
+    assert int(status[0]) == -2
+
+
+def test_inflate_device_pointers_full_size(eng, oracle):
+    import torch
+    n = 512
+    host = flate.synth("text", n, 65536)
+    off = flate.uniform_offsets(n, 65536)
+    d = torch.from_numpy(host).cuda()
+    comp, coff = eng.deflate_batch(d, off)
+    out, ooff, olen, status, err = eng.inflate_batch(comp, coff, [65536] * n)
+    assert (status == 0).all() and (olen == 65536).all()
+    assert torch.equal(out[:n * 65536], d)
