@@ -55,6 +55,12 @@ void flate_hip_destroy(flate_hip_ctx *ctx);
 /* Run on the caller's HIP stream (hipStream_t passed as void*), e.g. torch's
  * current stream; NULL = the ctx's own stream. */
 int flate_hip_set_stream(flate_hip_ctx *ctx, void *hip_stream);
+/* Tuning knobs of the match finder's launch geometry (results never change):
+ *   "guest_blocks"       extra persistent wavefronts whose hash table lives in L2 instead of LDS
+ *                        (default 4 per CU; 0 = off)
+ *   "resident_blocks"    persistent LDS-table wavefronts (default 5 per CU)
+ *   "guest_min_streams"  batches smaller than this use one block per stream (default 4096) */
+int flate_hip_set_option(flate_hip_ctx *ctx, const char *name, int64_t value);
 const char *flate_hip_strerror(int code);
 /* Text of the last HIP runtime error seen by this ctx ("" if none). */
 const char *flate_hip_last_hip_error(const flate_hip_ctx *ctx);

@@ -8,7 +8,8 @@ LIB_PATH = os.environ.get("FLATE_HIP_LIB") or os.path.join(HERE, "lib", "libflat
 
 # every symbol include/flate_hip.h declares
 EXPORTS = [
-    "flate_hip_init", "flate_hip_destroy", "flate_hip_set_stream", "flate_hip_strerror",
+    "flate_hip_init", "flate_hip_destroy", "flate_hip_set_stream", "flate_hip_set_option",
+    "flate_hip_strerror",
     "flate_hip_last_hip_error", "flate_hip_deflate_bound", "flate_hip_deflate_fast_batch",
     "flate_hip_lz77_matches", "flate_hip_inflate_batch", "flate_hip_set_profiling",
     "flate_hip_last_timing", "flate_hip_stage_name", "flate_hip_synth_fill",
@@ -40,6 +41,7 @@ def load():
     L.flate_hip_destroy.argtypes = [vp]
     L.flate_hip_destroy.restype = None
     L.flate_hip_set_stream.argtypes = [vp, vp]
+    L.flate_hip_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     L.flate_hip_strerror.argtypes = [C.c_int]
     L.flate_hip_strerror.restype = C.c_char_p
     L.flate_hip_last_hip_error.argtypes = [vp]

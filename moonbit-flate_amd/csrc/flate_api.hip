@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -40,7 +41,14 @@ struct flate_hip_ctx {
   // grow-only scratch
   DevBuf d_in, d_out, d_in_off, d_chunk_base, d_ids16, d_ids32, d_matches, d_nmatch, d_ntok;
   DevBuf d_slots, d_slot_off, d_out_len, d_out_off, d_status;
-  DevBuf d_istatus, d_ierr, d_debug;
+  DevBuf d_istatus, d_ierr, d_debug, d_gtables, d_queue;
+  hipStream_t guest_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int guest_blocks = 0;      // 0 = guest kernel off
+  float guest_share = 0.f;   // fraction of the single-window streams given to the guests
+  uint32_t guest_min = 4096; // below this many streams the guests stay idle
+  uint32_t resident_blocks = 1280;  // persistent LDS-table blocks (5 per CU x 256 CUs)
+  uint32_t queue_init = 0;
   uint32_t debug_chunks = 0;
 };
 
@@ -181,6 +189,17 @@ int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, cons
   P.chunk_ntok = (uint32_t *)c->d_ntok.p;
   P.compat_go = (flags & FLATE_HIP_COMPAT_GO) ? 1u : 0u;
   P.debug = nullptr;
+  P.gtables = nullptr;
+  P.queue = nullptr;
+  P.queue_end = 0;
+  if (c->guest_blocks > 0) {
+    if ((rc = ensure(c, c->d_gtables, (size_t)c->guest_blocks * kTableSize * 2 + 64))) return rc;
+    if ((rc = ensure(c, c->d_queue, 64))) return rc;
+    const uint32_t n16 = (uint32_t)pl.ids16.size();
+    (void)n16;
+    c->queue_init = 0;
+    HIP_TRY(c, hipMemcpyAsync(c->d_queue.p, &c->queue_init, 4, hipMemcpyHostToDevice, c->stream));
+  }
 #ifdef FLATE_LZ_STAMPS
   if ((rc = ensure(c, c->d_debug, (size_t)pl.n_chunks * 64 + 64))) return rc;
   HIP_TRY(c, hipMemsetAsync(c->d_debug.p, 0, (size_t)pl.n_chunks * 64, c->stream));
@@ -203,8 +222,25 @@ int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, cons
     } else {
       if (!pl.ids16.empty()) {
         P.stream_ids = (const uint32_t *)c->d_ids16.p;
-        hipLaunchKernelGGL(lz77_wave_kernel<uint16_t>, dim3((uint32_t)pl.ids16.size()), dim3(64),
-                           0, c->stream, P);
+        const uint32_t n16 = (uint32_t)pl.ids16.size();
+        const bool guests = c->guest_blocks > 0 && n16 >= c->guest_min;
+        if (guests) {
+          // fork: resident (LDS-table) and guest (L2-table) blocks pull streams from one queue
+          LzParams G = P;
+          G.gtables = c->d_gtables.p;
+          G.queue = (uint32_t *)c->d_queue.p;
+          G.queue_end = n16;
+          (void)hipEventRecord(c->ev_fork, c->stream);
+          (void)hipStreamWaitEvent(c->guest_stream, c->ev_fork, 0);
+          hipLaunchKernelGGL(lz77_guest_kernel<uint16_t>, dim3((uint32_t)c->guest_blocks), dim3(64), 0,
+                             c->guest_stream, G);
+          (void)hipEventRecord(c->ev_join, c->guest_stream);
+          const uint32_t resident = c->resident_blocks < n16 ? c->resident_blocks : n16;
+          hipLaunchKernelGGL(lz77_wave_kernel<uint16_t>, dim3(resident), dim3(64), 0, c->stream, G);
+          (void)hipStreamWaitEvent(c->stream, c->ev_join, 0);
+        } else {
+          hipLaunchKernelGGL(lz77_wave_kernel<uint16_t>, dim3(n16), dim3(64), 0, c->stream, P);
+        }
       }
       if (!pl.ids32.empty()) {
         P.stream_ids = (const uint32_t *)c->d_ids32.p;
@@ -262,6 +298,24 @@ int flate_hip_init(int device, flate_hip_ctx **out) {
     return FLATE_HIP_E_NO_DEVICE;
   }
   c->stream = c->own_stream;
+  if (hipStreamCreateWithFlags(&c->guest_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+    delete c;
+    return FLATE_HIP_E_HIP;
+  }
+  {  // 5 resident (LDS-table) + 4 guest (L2-table) match-finder waves per CU (measured best)
+    hipDeviceProp_t prop;
+    int cus = 256;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+    c->resident_blocks = 5u * (uint32_t)cus;
+    c->guest_blocks = 4 * cus;
+  }
+  if (const char *e = getenv("FLATE_HIP_GUEST_BLOCKS")) c->guest_blocks = atoi(e);
+  if (const char *e = getenv("FLATE_HIP_GUEST_SHARE")) c->guest_share = (float)atof(e);
+  if (const char *e = getenv("FLATE_HIP_GUEST_MIN")) c->guest_min = (uint32_t)atoi(e);
+  if (const char *e = getenv("FLATE_HIP_RESIDENT_BLOCKS")) c->resident_blocks = (uint32_t)atoi(e);
   for (auto &e : c->ev)
     if (hipEventCreate(&e) != hipSuccess) {
       delete c;
@@ -286,10 +340,13 @@ void flate_hip_destroy(flate_hip_ctx *c) {
   for (DevBuf *b : {&c->scan_tab, &c->d_in, &c->d_out, &c->d_in_off, &c->d_chunk_base, &c->d_ids16,
                     &c->d_ids32, &c->d_matches, &c->d_nmatch, &c->d_ntok, &c->d_slots,
                     &c->d_slot_off, &c->d_out_len, &c->d_out_off, &c->d_status, &c->d_istatus,
-                    &c->d_ierr, &c->d_debug})
+                    &c->d_ierr, &c->d_debug, &c->d_gtables, &c->d_queue})
     release(*b);
   for (auto &e : c->ev)
     if (e) (void)hipEventDestroy(e);
+  if (c->guest_stream) (void)hipStreamDestroy(c->guest_stream);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -297,6 +354,21 @@ void flate_hip_destroy(flate_hip_ctx *c) {
 int flate_hip_set_stream(flate_hip_ctx *c, void *hip_stream) {
   if (!c) return FLATE_HIP_E_INVALID;
   c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+  return FLATE_HIP_OK;
+}
+
+int flate_hip_set_option(flate_hip_ctx *c, const char *name, int64_t value) {
+  if (!c || !name) return FLATE_HIP_E_INVALID;
+  const std::string k(name);
+  if (k == "guest_blocks" && value >= 0 && value <= 65536) {
+    c->guest_blocks = (int)value;
+  } else if (k == "guest_min_streams" && value >= 0) {
+    c->guest_min = (uint32_t)value;
+  } else if (k == "resident_blocks" && value > 0 && value <= 65536) {
+    c->resident_blocks = (uint32_t)value;
+  } else {
+    return FLATE_HIP_E_INVALID;
+  }
   return FLATE_HIP_OK;
 }
 

@@ -21,6 +21,10 @@ struct LzParams {
   uint32_t *chunk_ntok;    // per chunk: literals + matches (DeflateFast::encode's token count)
   uint32_t compat_go;
   uint64_t *debug;  // diagnostic builds only (8 u64 per chunk), else null
+  // guest kernel only
+  void *gtables;        // one table per guest block
+  uint32_t *queue;      // next index into stream_ids
+  uint32_t queue_end;
 };
 
 struct HuffParams {
@@ -63,6 +67,8 @@ struct InfParams {
 __global__ void lz77_serial_kernel(LzParams P);
 template <typename E>
 __global__ void lz77_wave_kernel(LzParams P);
+template <typename E>
+__global__ void lz77_guest_kernel(LzParams P);
 __global__ void huff_pack_kernel(HuffParams P);
 __global__ void scan_sizes_kernel(CompactParams P);
 __global__ void compact_kernel(CompactParams P);

@@ -237,11 +237,10 @@ FLATE_D int extend_match(const uint8_t *src, const uint8_t *stream, uint32_t W, 
   return have + 4 * k + (__builtin_ctz(rdlane(x, k)) >> 3);
 }
 
+// One stream, start to finish.  `table` is the 16384-slot position table of this stream: LDS for
+// the resident kernel, a per-block slice of HBM (L2-resident) for the guest kernel.
 template <typename E>
-__global__ __launch_bounds__(64) void lz77_wave_kernel(LzParams P) {
-  __shared__ E table[kTableSize];
-  const int lane = threadIdx.x;
-  const uint32_t sid = P.stream_ids ? P.stream_ids[blockIdx.x] : blockIdx.x;
+FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, E *table, const int lane) {
   {
     uint4 *t4 = reinterpret_cast<uint4 *>(table);
     const uint4 z = make_uint4(0, 0, 0, 0);
@@ -621,7 +620,48 @@ __global__ __launch_bounds__(64) void lz77_wave_kernel(LzParams P) {
   }
 }
 
+// Resident kernel: table in LDS (32 or 64 KiB per stream => 5 or 2 streams per CU).
+template <typename E>
+__global__ __launch_bounds__(64) void lz77_wave_kernel(LzParams P) {
+  __shared__ E table[kTableSize];
+  const int lane = threadIdx.x;
+  if (!P.queue) {  // one block per stream
+    const uint32_t sid = P.stream_ids ? P.stream_ids[blockIdx.x] : blockIdx.x;
+    lz77_stream<E>(P, sid, table, lane);
+    return;
+  }
+  for (;;) {  // persistent: resident and guest blocks share one queue (dynamic balance)
+    uint32_t q = 0;
+    if (lane == 0) q = atomicAdd(P.queue, 1u);
+    q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
+    if (q >= P.queue_end) break;
+    __syncthreads();
+    lz77_stream<E>(P, P.stream_ids[q], table, lane);
+    __syncthreads();
+  }
+}
+
+// Guest kernel: the LDS of a CU holds only five 32 KiB tables, but its SIMDs are mostly idle
+// (the parser is latency-bound).  A small persistent grid of extra wavefronts runs the same
+// parser with tables in HBM scratch -- few enough that those tables stay in the 4 MiB L2 of
+// their XCD -- and pulls streams from a queue.
+template <typename E>
+__global__ __launch_bounds__(64) void lz77_guest_kernel(LzParams P) {
+  E *table = reinterpret_cast<E *>(P.gtables) + (size_t)blockIdx.x * kTableSize;
+  const int lane = threadIdx.x;
+  for (;;) {
+    uint32_t q = 0;
+    if (lane == 0) q = atomicAdd(P.queue, 1u);
+    q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
+    if (q >= P.queue_end) break;
+    __syncthreads();
+    lz77_stream<E>(P, P.stream_ids[q], table, lane);
+    __syncthreads();
+  }
+}
+
 template __global__ void lz77_wave_kernel<uint16_t>(LzParams);
 template __global__ void lz77_wave_kernel<uint32_t>(LzParams);
+template __global__ void lz77_guest_kernel<uint16_t>(LzParams);
 
 }  // namespace flate

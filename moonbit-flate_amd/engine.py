@@ -90,6 +90,10 @@ class FlateEngine:
         """Launch on the given hipStream_t (int address), e.g. torch.cuda.current_stream().cuda_stream."""
         self._check(self._L.flate_hip_set_stream(self._ctx, C.c_void_p(hip_stream_ptr or None)))
 
+    def set_option(self, name, value):
+        """Launch-geometry knobs (guest_blocks, resident_blocks, guest_min_streams)."""
+        self._check(self._L.flate_hip_set_option(self._ctx, name.encode(), int(value)))
+
     def set_profiling(self, on=True):
         self._check(self._L.flate_hip_set_profiling(self._ctx, 1 if on else 0))
 

@@ -132,6 +132,21 @@ def test_fuzz_random_lengths(eng, oracle):
     _check_streams(eng, oracle, specs)
 
 
+def test_guest_blocks_give_identical_streams(oracle):
+    # resident (LDS-table) and guest (L2-table) match-finder blocks share one stream queue
+    e = flate.FlateEngine(0)
+    try:
+        e.set_option("guest_min_streams", 1)
+        e.set_option("guest_blocks", 8)
+        e.set_option("resident_blocks", 4)
+        _check_streams(e, oracle, SINGLE_WINDOW + MULTI_WINDOW + [("text", 65536)] * 40)
+        e.set_option("resident_blocks", 1)
+        e.set_option("guest_blocks", 64)
+        _check_streams(e, oracle, [("text", 65536), ("runs", 65536), ("low", 65536)] * 20)
+    finally:
+        e.close()
+
+
 def test_out_too_small_is_reported(eng):
     data, off = make_streams([("rand", 65536)] * 4)
     with pytest.raises(flate.FlateError) as ei:
