@@ -1,6 +1,7 @@
-// compact_kernels.hip -- gathers the per-stream output slots into one contiguous
-// buffer and produces the (N+1)-entry offset index.  The reference has no container
-// format: each stream is an independent DEFLATE stream ending in BFINAL.
+// compact_kernels.hip -- the (N+1)-entry offset index of the output: an exclusive scan of the
+// exact per-stream sizes, so that huff_pack_kernel can write every stream in its final place.
+// The reference has no container format: each stream is an independent DEFLATE
+// stream ending in BFINAL; streams are laid out back to back.
 #include "flate_kernels.h"
 
 namespace flate {
@@ -34,30 +35,6 @@ __global__ __launch_bounds__(1024) void scan_sizes_kernel(CompactParams P) {
     P.out_off[P.n_streams] = carry_s;
     if (carry_s > P.out_cap) *P.status = -2;  // FLATE_HIP_E_OUT_TOO_SMALL
   }
-}
-
-// One workgroup per stream: slot (16-byte aligned) -> out + out_off[i] (any alignment).
-__global__ __launch_bounds__(256) void compact_kernel(CompactParams P) {
-  if (*P.status != 0) return;
-  const uint32_t sid = blockIdx.x;
-  const uint64_t len = P.out_len[sid];
-  const uint8_t *src = P.slots + P.slot_off[sid];
-  uint8_t *dst = P.out + P.out_off[sid];
-  const int tid = threadIdx.x;
-  // head: bytes until dst is 4-byte aligned
-  uint64_t head = (4 - ((uintptr_t)dst & 3)) & 3;
-  if (head > len) head = len;
-  if ((uint64_t)tid < head) dst[tid] = src[tid];
-  const uint64_t body = (len - head) >> 2;  // dwords
-  const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
-  uint32_t *d32 = reinterpret_cast<uint32_t *>(dst + head);
-  const uint32_t shift = (uint32_t)head;  // src byte offset of d32[0] (0..3); src is aligned
-  for (uint64_t j = tid; j < body; j += 256) {
-    const uint32_t lo = s32[j], hi = shift ? s32[j + 1] : 0u;
-    d32[j] = shift ? __builtin_amdgcn_alignbyte(hi, lo, shift) : lo;
-  }
-  const uint64_t done = head + (body << 2);
-  if ((uint64_t)tid < len - done) dst[done + tid] = src[done + tid];
 }
 
 }  // namespace flate

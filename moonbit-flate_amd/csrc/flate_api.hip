@@ -40,7 +40,8 @@ struct flate_hip_ctx {
   int scan_len = 0;
   // grow-only scratch
   DevBuf d_in, d_out, d_in_off, d_chunk_base, d_ids16, d_ids32, d_matches, d_nmatch, d_ntok;
-  DevBuf d_slots, d_slot_off, d_out_len, d_out_off, d_status;
+  DevBuf d_slot_off, d_out_len, d_out_off, d_status;
+  DevBuf d_blk_base, d_blk_hist, d_blk_cl, d_blk_hdr, d_blk_meta;
   DevBuf d_istatus, d_ierr, d_debug, d_gtables, d_queue;
   hipStream_t guest_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -98,15 +99,16 @@ struct StagePlan {
   uint32_t n_streams = 0;
   std::vector<uint32_t> chunk_base;  // n+1
   std::vector<uint32_t> ids16, ids32;
-  std::vector<uint64_t> slot_off;  // n+1
+  std::vector<uint32_t> blk_base;  // n+1
   uint32_t n_chunks = 0;
+  uint32_t n_blocks = 0;
 };
 
 int make_plan(const uint64_t *in_off, uint32_t n, StagePlan &pl) {
   pl.n_streams = n;
   pl.chunk_base.resize((size_t)n + 1);
-  pl.slot_off.resize((size_t)n + 1);
-  uint64_t chunks = 0, slot = 0;
+  pl.blk_base.resize((size_t)n + 1);
+  uint64_t chunks = 0, blocks = 0;
   for (uint32_t i = 0; i < n; ++i) {
     if (in_off[i + 1] < in_off[i]) return FLATE_HIP_E_INVALID;
     const uint64_t len = in_off[i + 1] - in_off[i];
@@ -114,7 +116,7 @@ int make_plan(const uint64_t *in_off, uint32_t n, StagePlan &pl) {
     const uint64_t full = len / kMaxStoreBlockSize, r = len % kMaxStoreBlockSize;
     const uint64_t nch = full + (r >= (uint64_t)kSmallLzMin ? 1 : 0);
     pl.chunk_base[i] = (uint32_t)chunks;
-    pl.slot_off[i] = slot;
+    pl.blk_base[i] = (uint32_t)blocks;
     if (nch == 1) {
       pl.ids16.push_back(i);  // one LZ77 window (it starts at 0): positions fit a 16-bit slot
     } else if (nch > 0) {
@@ -122,11 +124,13 @@ int make_plan(const uint64_t *in_off, uint32_t n, StagePlan &pl) {
     }
     chunks += nch;
     if (chunks > 0xffffffffull) return FLATE_HIP_E_TOO_LARGE;
-    slot += (flate_hip_deflate_bound((size_t)len) + 4 + 15) & ~15ull;
+    blocks += full + (r > 0 ? 1 : 0);
+    if (blocks > 0xffffffffull) return FLATE_HIP_E_TOO_LARGE;
   }
   pl.chunk_base[n] = (uint32_t)chunks;
-  pl.slot_off[n] = slot;
+  pl.blk_base[n] = (uint32_t)blocks;
   pl.n_chunks = (uint32_t)chunks;
+  pl.n_blocks = (uint32_t)blocks;
   return FLATE_HIP_OK;
 }
 
@@ -279,7 +283,7 @@ const char *flate_hip_stage_name(int stage) {
   switch (stage) {
     case FLATE_HIP_STAGE_LZ77: return "lz77_match";
     case FLATE_HIP_STAGE_HUFF_PACK: return "huff_pack";
-    case FLATE_HIP_STAGE_COMPACT: return "compact";
+    case FLATE_HIP_STAGE_COMPACT: return "compact";  // unused since the pack kernel writes in place
     case FLATE_HIP_STAGE_INFLATE: return "inflate";
     default: return "?";
   }
@@ -338,8 +342,8 @@ void flate_hip_destroy(flate_hip_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
   for (DevBuf *b : {&c->scan_tab, &c->d_in, &c->d_out, &c->d_in_off, &c->d_chunk_base, &c->d_ids16,
-                    &c->d_ids32, &c->d_matches, &c->d_nmatch, &c->d_ntok, &c->d_slots,
-                    &c->d_slot_off, &c->d_out_len, &c->d_out_off, &c->d_status, &c->d_istatus,
+                    &c->d_ids32, &c->d_matches, &c->d_nmatch, &c->d_ntok, &c->d_blk_base,
+                    &c->d_blk_hist, &c->d_blk_cl, &c->d_blk_hdr, &c->d_blk_meta, &c->d_slot_off, &c->d_out_len, &c->d_out_off, &c->d_status, &c->d_istatus,
                     &c->d_ierr, &c->d_debug, &c->d_gtables, &c->d_queue})
     release(*b);
   for (auto &e : c->ev)
@@ -418,11 +422,15 @@ int flate_hip_deflate_fast_batch(flate_hip_ctx *c, const uint8_t *in, const uint
   }
   if ((rc = run_lz77(c, d_in, in_off, pl, flags))) return rc;
 
-  if ((rc = ensure(c, c->d_slots, pl.slot_off[n] + 64))) return rc;
-  if ((rc = ensure(c, c->d_slot_off, ((size_t)n + 1) * 8))) return rc;
+  const size_t nb = (size_t)pl.n_blocks + 1;
+  if ((rc = ensure(c, c->d_blk_base, ((size_t)n + 1) * 4))) return rc;
+  if ((rc = ensure(c, c->d_blk_hist, nb * 320 * 4))) return rc;
+  if ((rc = ensure(c, c->d_blk_cl, nb * 320 * 4))) return rc;
+  if ((rc = ensure(c, c->d_blk_hdr, nb * 704 * 4))) return rc;
+  if ((rc = ensure(c, c->d_blk_meta, nb * 16))) return rc;
   if ((rc = ensure(c, c->d_out_len, (size_t)n * 8 + 8))) return rc;
   if ((rc = ensure(c, c->d_out_off, ((size_t)n + 1) * 8))) return rc;
-  HIP_TRY(c, hipMemcpyAsync(c->d_slot_off.p, pl.slot_off.data(), ((size_t)n + 1) * 8,
+  HIP_TRY(c, hipMemcpyAsync(c->d_blk_base.p, pl.blk_base.data(), ((size_t)n + 1) * 4,
                             hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemsetAsync(c->d_status.p, 0, 4, c->stream));
 
@@ -430,40 +438,32 @@ int flate_hip_deflate_fast_batch(flate_hip_ctx *c, const uint8_t *in, const uint
   H.in = d_in;
   H.in_off = (const uint64_t *)c->d_in_off.p;
   H.chunk_base = (const uint32_t *)c->d_chunk_base.p;
+  H.blk_base = (const uint32_t *)c->d_blk_base.p;
   H.matches = (const uint2 *)c->d_matches.p;
   H.chunk_nmatch = (const uint32_t *)c->d_nmatch.p;
   H.chunk_ntok = (const uint32_t *)c->d_ntok.p;
-  H.slots = (uint8_t *)c->d_slots.p;
-  H.slot_off = (const uint64_t *)c->d_slot_off.p;
+  H.blk_hist = (uint32_t *)c->d_blk_hist.p;
+  H.blk_cl = (uint32_t *)c->d_blk_cl.p;
+  H.blk_hdr = (uint32_t *)c->d_blk_hdr.p;
+  H.blk_meta = (uint4 *)c->d_blk_meta.p;
   H.out_len = (uint64_t *)c->d_out_len.p;
+  H.out_off = (const uint64_t *)c->d_out_off.p;
+  H.out = d_out;
+  H.status = (int *)c->d_status.p;
   H.n_streams = n;
   H.compat_go = (flags & FLATE_HIP_COMPAT_GO) ? 1u : 0u;
-  H.debug = nullptr;
-#ifdef FLATE_HP_STAMPS
-  if ((rc = ensure(c, c->d_debug, (size_t)n * 64 + 64))) return rc;
-  HIP_TRY(c, hipMemsetAsync(c->d_debug.p, 0, (size_t)n * 64, c->stream));
-  H.debug = (uint64_t *)c->d_debug.p;
-  c->debug_chunks = n;
-#endif
-  {
-    StageTimer t(c, FLATE_HIP_STAGE_HUFF_PACK);
-    hipLaunchKernelGGL(huff_pack_kernel, dim3(n), dim3(64), 0, c->stream, H);
-  }
-  HIP_TRY(c, hipGetLastError());
-
   CompactParams C;
-  C.slots = (const uint8_t *)c->d_slots.p;
-  C.slot_off = (const uint64_t *)c->d_slot_off.p;
   C.out_len = (const uint64_t *)c->d_out_len.p;
   C.out_off = (uint64_t *)c->d_out_off.p;
-  C.out = d_out;
   C.out_cap = out_cap;
   C.n_streams = n;
   C.status = (int *)c->d_status.p;
   {
-    StageTimer t(c, FLATE_HIP_STAGE_COMPACT);
+    StageTimer t(c, FLATE_HIP_STAGE_HUFF_PACK);
+    hipLaunchKernelGGL(huff_hist_kernel, dim3(n), dim3(64), 0, c->stream, H);
+    hipLaunchKernelGGL(huff_code_kernel, dim3(n), dim3(64), 0, c->stream, H);
     hipLaunchKernelGGL(scan_sizes_kernel, dim3(1), dim3(1024), 0, c->stream, C);
-    hipLaunchKernelGGL(compact_kernel, dim3(n), dim3(256), 0, c->stream, C);
+    hipLaunchKernelGGL(huff_pack_kernel, dim3(n), dim3(64), 0, c->stream, H);
   }
   HIP_TRY(c, hipGetLastError());
 
@@ -477,7 +477,7 @@ int flate_hip_deflate_fast_batch(flate_hip_ctx *c, const uint8_t *in, const uint
     HIP_TRY(c, hipMemcpyAsync(out, c->d_out.p, out_off[n], hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
   }
-  const bool used[FLATE_HIP_STAGE_COUNT] = {true, true, true, false};
+  const bool used[FLATE_HIP_STAGE_COUNT] = {true, true, false, false};
   return collect_timing(c, used);
 }
 

@@ -27,27 +27,32 @@ struct LzParams {
   uint32_t queue_end;
 };
 
+// Entropy stage.  Blocks are the units enc_speed writes: every full 65535-byte window plus the
+// tail (blk_base[i] .. blk_base[i+1] are stream i's blocks; the first chunk_base[i+1]-chunk_base[i]
+// of them are LZ77 chunks).
 struct HuffParams {
   const uint8_t *in;
   const uint64_t *in_off;
   const uint32_t *chunk_base;
+  const uint32_t *blk_base;  // n_streams + 1
   const uint2 *matches;
   const uint32_t *chunk_nmatch;
   const uint32_t *chunk_ntok;
-  uint8_t *slots;            // per-stream output slots (16-byte aligned)
-  const uint64_t *slot_off;  // n_streams + 1
-  uint64_t *out_len;         // bytes produced per stream
+  uint32_t *blk_hist;  // per block 320 u32: literal/length histogram [0,286), offsets [288,318)
+  uint32_t *blk_cl;    // per block 320 u32: (len << 16) | bit-reversed code, same layout
+  uint32_t *blk_hdr;   // per block 704 u32: dynamic-header items (nbits << 16) | value
+  uint4 *blk_meta;     // per block {kind 0 stored / 1 huffman-only / 2 dynamic, header items, start bit lo, hi}
+  uint64_t *out_len;   // exact compressed bytes per stream (huff_code_kernel)
+  const uint64_t *out_off;  // exclusive scan of out_len
+  uint8_t *out;
+  int *status;
   uint32_t n_streams;
   uint32_t compat_go;
-  uint64_t *debug;  // diagnostic builds only (8 u64 per stream), else null
 };
 
 struct CompactParams {
-  const uint8_t *slots;
-  const uint64_t *slot_off;
   const uint64_t *out_len;
   uint64_t *out_off;  // n_streams + 1 (device), exclusive scan of out_len
-  uint8_t *out;
   uint64_t out_cap;
   uint32_t n_streams;
   int *status;  // set to FLATE_HIP_E_OUT_TOO_SMALL if the total exceeds out_cap
@@ -69,9 +74,10 @@ template <typename E>
 __global__ void lz77_wave_kernel(LzParams P);
 template <typename E>
 __global__ void lz77_guest_kernel(LzParams P);
+__global__ void huff_hist_kernel(HuffParams P);
+__global__ void huff_code_kernel(HuffParams P);
 __global__ void huff_pack_kernel(HuffParams P);
 __global__ void scan_sizes_kernel(CompactParams P);
-__global__ void compact_kernel(CompactParams P);
 __global__ void inflate_kernel(InfParams P);
 
 }  // namespace flate

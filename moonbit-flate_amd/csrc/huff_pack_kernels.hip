@@ -8,8 +8,13 @@
 //                                       huffman-bit-writer.mbt:550-593,241-330,335-360,421-471,596-731
 //   HuffmanEncoder::generate            huffman-code.mbt:295-343
 //
-// One wavefront per stream.  Everything that is a loop over tokens or symbols in the
-// reference is a wave-parallel pass here:
+// Three kernels, one wavefront per stream each, split so that every phase runs at the
+// occupancy its LDS footprint allows:
+//   huff_hist_kernel  index_tokens: per-block symbol histograms          (~2 KiB LDS)
+//   huff_code_kernel  code construction, header, exact block bit sizes   (~15 KiB LDS, short)
+//   huff_pack_kernel  write_dynamic_header + write_tokens, straight into the final
+//                     output at the offsets given by a scan of the exact sizes (~3 KiB LDS)
+// Everything that is a loop over tokens or symbols in the reference is a wave-parallel pass:
 //  * the token sequence is never materialised: each lane owns one input position of a
 //    64-byte tile and decides from the (sorted) match records whether it is a literal,
 //    the start of a match, or covered by one;
@@ -40,6 +45,7 @@ constexpr int kHdrMax = 704;
 // codegen_order, huffman-bit-writer.mbt:83-85 (RFC 1951 3.2.7)
 __constant__ uint8_t kCodegenOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
+// LDS of huff_code_kernel
 struct Shared {
   uint32_t lit_freq[288];
   uint32_t off_freq[32];
@@ -63,11 +69,21 @@ struct Shared {
   uint16_t hdr_val[kHdrMax];
   uint8_t hdr_nb[kHdrMax];
   uint32_t hdr_n;
+};
+
+// LDS of huff_hist_kernel
+struct SharedHist {
+  uint32_t lit_freq[288];
+  uint32_t off_freq[32];
   uint2 tile[64];  // per-tile scatter target: {token starting here, coverage mark +1/-1}
+};
+
+// LDS of huff_pack_kernel
+struct SharedPack {
+  uint32_t lit_cl[288];
+  uint32_t off_cl[32];
+  uint2 tile[64];
   uint32_t ring[kRing];
-#ifdef FLATE_HP_STAMPS
-  uint64_t st[8];
-#endif
 };
 
 FLATE_D uint32_t rdlane(uint32_t v, int lane) {
@@ -97,12 +113,31 @@ FLATE_D uint32_t wave_max(uint32_t v) {
 }
 
 // ---- bit sink ----------------------------------------------------------------------
+// The stream's bytes start at an arbitrary address: out32 is that address rounded down to a
+// dword and bitpos starts at 8 * misalignment.  Dwords that contain a byte of a neighbouring
+// stream (the first one if misaligned, the last one if the stream ends inside it) are written
+// byte by byte, everything else with coalesced dword stores.
 struct BitSink {
   uint32_t *ring;    // LDS, zero outside the pending window
-  uint32_t *out32;   // global slot, 4-byte aligned
-  uint64_t bitpos;   // bits written so far
+  uint32_t *out32;   // 4-byte aligned
+  uint64_t bitpos;   // bit position relative to out32
   uint32_t flushed;  // dwords already drained to out32
+  uint32_t head;     // bytes of dword 0 that belong to the previous stream (0..3)
+  uint32_t last_dw;  // dword holding the stream's last byte
+  uint32_t tail;     // bytes of last_dw that belong to this stream (1..4)
 };
+
+FLATE_D void sink_store(const BitSink &S, uint32_t idx, uint32_t v) {
+  const bool first = idx == 0 && S.head != 0;
+  const bool last = idx == S.last_dw && S.tail != 4;
+  if (!first && !last) {
+    S.out32[idx] = v;
+    return;
+  }
+  uint8_t *b = reinterpret_cast<uint8_t *>(S.out32 + idx);
+  const uint32_t lo = first ? S.head : 0u, hi = last ? S.tail : 4u;
+  for (uint32_t k = lo; k < hi; ++k) b[k] = (uint8_t)(v >> (8 * k));
+}
 
 // Every lane appends nb (<= 48) bits, in lane order.
 FLATE_D void sink_emit(BitSink &S, uint64_t bits, uint32_t nb, int lane) {
@@ -124,7 +159,7 @@ FLATE_D void sink_emit(BitSink &S, uint64_t bits, uint32_t nb, int lane) {
   __syncthreads();
   while ((uint32_t)(S.bitpos >> 5) - S.flushed >= 64u) {
     const uint32_t idx = S.flushed + (uint32_t)lane;
-    S.out32[idx] = S.ring[idx & (kRing - 1)];
+    sink_store(S, idx, S.ring[idx & (kRing - 1)]);
     S.ring[idx & (kRing - 1)] = 0;
     S.flushed += 64;
   }
@@ -140,7 +175,7 @@ FLATE_D void sink_finish(BitSink &S, int lane) {
   while (S.flushed < end) {
     const uint32_t idx = S.flushed + (uint32_t)lane;
     if (idx < end) {
-      S.out32[idx] = S.ring[idx & (kRing - 1)];
+      sink_store(S, idx, S.ring[idx & (kRing - 1)]);
       S.ring[idx & (kRing - 1)] = 0;
     }
     S.flushed += 64;
@@ -352,7 +387,7 @@ FLATE_D Walker walker_init(const uint8_t *src, const uint2 *recs, uint32_t nm, i
   return w;
 }
 
-FLATE_D TileTok walk_tile(Shared &sh, Walker &w, int P0, int lane) {
+FLATE_D TileTok walk_tile(uint2 *tile, Walker &w, int P0, int lane) {
   TileTok t;
   const int pos = P0 + lane;
   const uint2 rec = w.rec;
@@ -365,17 +400,17 @@ FLATE_D TileTok walk_tile(Shared &sh, Walker &w, int P0, int lane) {
   w.byte = load_byte(w, pos + 64);
   // scatter the tile's matches: token at its start position, +1 at the first covered
   // position, -1 just past the match; a prefix sum of the marks is the coverage
-  sh.tile[lane] = make_uint2(0u, 0u);
+  tile[lane] = make_uint2(0u, 0u);
   __syncthreads();
   const uint32_t mlen = ((rec.y >> kLengthShift) & 0xffu) + 3u;
   if (mine) {
     const uint32_t o = rec.x - (uint32_t)P0;
-    sh.tile[o].x = rec.y;
-    if (o + 1 < 64u) sh.tile[o + 1].y = 1u;
-    if (o + mlen < 64u) sh.tile[o + mlen].y = 0xffffffffu;
+    tile[o].x = rec.y;
+    if (o + 1 < 64u) tile[o + 1].y = 1u;
+    if (o + mlen < 64u) tile[o + mlen].y = 0xffffffffu;
   }
   __syncthreads();
-  const uint2 tl = sh.tile[lane];
+  const uint2 tl = tile[lane];
   const uint32_t cover = wave_incl_scan(tl.y);
   const bool covered = (uint32_t)pos < w.cov_until || cover != 0;
   if (cnt) w.cov_until = rdlane(rec.x, cnt - 1) + rdlane(mlen, cnt - 1);
@@ -385,17 +420,6 @@ FLATE_D TileTok walk_tile(Shared &sh, Walker &w, int P0, int lane) {
   t.is_match = active && tl.x != 0;
   t.is_lit = active && !covered && tl.x == 0;
   return t;
-}
-
-// Emit the dynamic header (huffman-bit-writer.mbt:421-471) from hdr_val/hdr_nb.
-FLATE_D void emit_items(Shared &sh, BitSink &S, int lane) {
-  const int n = (int)sh.hdr_n;
-  for (int base = 0; base < n; base += 64) {
-    const int i = base + lane;
-    const uint32_t nb = i < n ? sh.hdr_nb[i] : 0u;
-    const uint64_t v = i < n ? sh.hdr_val[i] : 0u;
-    sink_emit(S, v, nb, lane);
-  }
 }
 
 // stored block: header, pad, LEN, ~LEN, raw bytes (huffman-bit-writer.mbt:474-487,202-225)
@@ -513,201 +537,281 @@ FLATE_D bool prefer_stored(uint32_t compat_go, int n, uint32_t size) {
   return ssize < ((size + size) >> 4);               // huffman-bit-writer.mbt:527,780
 }
 
-// write_block_huff (:738-824): literal-only block over src[0..n)
-FLATE_D void block_huff(Shared &sh, BitSink &S, const HuffParams &P, const uint8_t *src, int n,
-                        int lane) {
-  for (int i = lane; i < 288; i += 64) sh.lit_freq[i] = 0;
-  __syncthreads();
-  {
-    uint32_t nxt = lane < n ? src[lane] : 0u;
-    for (int base = 0; base < n; base += 64) {
-      const int i = base + lane;
-      const uint32_t bt = nxt;
-      nxt = i + 64 < n ? src[i + 64] : 0u;
-      if (i < n) atomicAdd(&sh.lit_freq[bt], 1u);
-    }
-  }
-  __syncthreads();
-  if (lane == 0) sh.lit_freq[kEndBlockMarker] = 1;
-  __syncthreads();
-  build_code(sh, sh.lit_freq, kMaxNumLit, 15, sh.lit_cl, lane);
-  // huff_offset (huffman-code.mbt:691-726): code 0 has length 1, nothing else
-  if (lane < 32) sh.off_cl[lane] = lane == 0 ? (1u << 16) : 0u;
-  __syncthreads();
-  uint32_t size = make_header(sh, kEndBlockMarker + 1, 1, lane);
-  uint32_t part = 0;
-  for (int i = lane; i < kMaxNumLit; i += 64) part += sh.lit_freq[i] * (sh.lit_cl[i] >> 16);
-  size += wave_sum(part) + 1u;  // + offset_freq[0] (=1) * 1 bit
-  if (prefer_stored(P.compat_go, n, size)) {
-    emit_stored(S, src, n, false, lane);
-    return;
-  }
-  emit_items(sh, S, lane);
-  {
-    uint32_t nxt = lane < n ? src[lane] : 0u;
-    for (int base = 0; base < n; base += 64) {
-      const int i = base + lane;
-      const uint32_t bt = nxt;
-      nxt = i + 64 < n ? src[i + 64] : 0u;
-      const uint32_t c = i < n ? sh.lit_cl[bt] : 0u;
-      sink_emit(S, c & 0xffffu, c >> 16, lane);
-    }
-  }
-  const uint32_t eob = sh.lit_cl[kEndBlockMarker];
-  sink_emit(S, eob & 0xffffu, lane == 0 ? (eob >> 16) : 0u, lane);
+constexpr int kBlkStride = 320;  // u32 per block in blk_hist / blk_cl: 288 lit + 32 off
+
+struct BlockGeom {
+  const uint8_t *stream;
+  uint64_t len, full;
+  int r;
+  uint32_t nblocks, blk0, chunk0;
+};
+FLATE_D BlockGeom block_geom(const HuffParams &P, uint32_t sid) {
+  BlockGeom g;
+  const uint64_t a = P.in_off[sid];
+  g.len = P.in_off[sid + 1] - a;
+  g.stream = P.in + a;
+  g.full = g.len / (uint64_t)kMaxStoreBlockSize;
+  g.r = (int)(g.len % (uint64_t)kMaxStoreBlockSize);
+  g.nblocks = (uint32_t)g.full + (g.r > 0 ? 1u : 0u);
+  g.blk0 = P.blk_base[sid];
+  g.chunk0 = P.chunk_base[sid];
+  return g;
 }
 
-// write_block_dynamic (:496-542) over the implied token sequence of one LZ77 chunk
-FLATE_D void block_dynamic(Shared &sh, BitSink &S, const HuffParams &P, const uint8_t *src, int n,
-                           const uint2 *recs, uint32_t nm, int lane) {
-  HSTAMP(h0);
-  for (int i = lane; i < 288; i += 64) sh.lit_freq[i] = 0;
-  if (lane < 32) sh.off_freq[lane] = 0;
-  __syncthreads();
-  // index_tokens (:550-593)
-  {
-    Walker w = walker_init(src, recs, nm, n, lane);
-    for (int P0 = 0; P0 < n; P0 += 64) {
-      const TileTok t = walk_tile(sh, w, P0, lane);
-      if (t.is_match) {
-        const CodeBits lc = length_code_of((t.tok >> kLengthShift) & 0xffu);
-        const CodeBits oc = offset_code_of(t.tok & ((1u << kLengthShift) - 1u));
-        atomicAdd(&sh.lit_freq[kLengthCodesStart + lc.code], 1u);
-        atomicAdd(&sh.off_freq[oc.code], 1u);
-      } else if (t.is_lit) {
-        atomicAdd(&sh.lit_freq[t.byte], 1u);
-      }
-    }
-    if (lane == 0) atomicAdd(&sh.lit_freq[kEndBlockMarker], 1u);  // tokens.push(EOB), :507
-  }
-  __syncthreads();
-  HSTAMP(h1);
-  int num_literals, num_offsets;
-  {
-    uint32_t hi = 0;
-    for (int i = lane; i < kMaxNumLit; i += 64)
-      if (sh.lit_freq[i]) hi = (uint32_t)i + 1;
-    num_literals = (int)wave_max(hi);
-    uint32_t ho = (lane < kOffsetCodeCount && sh.off_freq[lane]) ? (uint32_t)lane + 1 : 0u;
-    num_offsets = (int)wave_max(ho);
-    if (num_offsets == 0) {  // :584-589
-      if (lane == 0) sh.off_freq[0] = 1;
-      num_offsets = 1;
-    }
-  }
-  __syncthreads();
-  build_code(sh, sh.lit_freq, kMaxNumLit, 15, sh.lit_cl, lane);
-  HSTAMP(h2);
-  build_code(sh, sh.off_freq, kOffsetCodeCount, 15, sh.off_cl, lane);
-  HSTAMP(h3);
-  uint32_t size = make_header(sh, num_literals, num_offsets, lane);
-  HSTAMP(h4);
-  {
-    uint32_t part = 0;
-    for (int i = lane; i < kMaxNumLit; i += 64) part += sh.lit_freq[i] * (sh.lit_cl[i] >> 16);
-    if (lane < kOffsetCodeCount) part += sh.off_freq[lane] * (sh.off_cl[lane] >> 16);
-    size += wave_sum(part);  // extra bits are NOT counted (callers pass 0, :519-523)
-  }
-  if (prefer_stored(P.compat_go, n, size)) {
-    emit_stored(S, src, n, false, lane);
-    return;
-  }
-  emit_items(sh, S, lane);
-  HSTAMP(h5);
-  // write_tokens (:596-731)
-  Walker w = walker_init(src, recs, nm, n, lane);
-  for (int P0 = 0; P0 < n; P0 += 64) {
-    const TileTok t = walk_tile(sh, w, P0, lane);
-    uint64_t bits = 0;
-    uint32_t nb = 0;
-    if (t.is_match) {
-      const CodeBits lc = length_code_of((t.tok >> kLengthShift) & 0xffu);
-      const CodeBits oc = offset_code_of(t.tok & ((1u << kLengthShift) - 1u));
-      const uint32_t c1 = sh.lit_cl[kLengthCodesStart + lc.code];
-      const uint32_t c2 = sh.off_cl[oc.code];
-      bits = c1 & 0xffffu;
-      nb = c1 >> 16;
-      bits |= (uint64_t)lc.extra << nb;
-      nb += lc.nextra;
-      bits |= (uint64_t)(c2 & 0xffffu) << nb;
-      nb += c2 >> 16;
-      bits |= (uint64_t)oc.extra << nb;
-      nb += oc.nextra;
-    } else if (t.is_lit) {
-      const uint32_t c = sh.lit_cl[t.byte];
-      bits = c & 0xffffu;
-      nb = c >> 16;
-    }
-    sink_emit(S, bits, nb, lane);
-  }
-  const uint32_t eob = sh.lit_cl[kEndBlockMarker];
-  sink_emit(S, eob & 0xffffu, lane == 0 ? (eob >> 16) : 0u, lane);
-  HSTAMP(h6);
-  HSTAMP_ADD(0, h1, h0);
-  HSTAMP_ADD(1, h2, h1);
-  HSTAMP_ADD(2, h3, h2);
-  HSTAMP_ADD(3, h4, h3);
-  HSTAMP_ADD(4, h5, h4);
-  HSTAMP_ADD(5, h6, h5);
-}
+// extra bits carried by length code c / offset code c (huffman-bit-writer.mbt:49-54,67-70)
+FLATE_D uint32_t len_extra_of_code(uint32_t c) { return (c < 8 || c >= 28) ? 0u : (c >> 2) - 1u; }
+FLATE_D uint32_t off_extra_of_code(uint32_t c) { return c < 4 ? 0u : (c >> 1) - 1u; }
 
 }  // namespace
 
-__global__ __launch_bounds__(64) void huff_pack_kernel(HuffParams P) {
+// ---------------------------------------------------------------------------------------
+// index_tokens (:550-593) / histogram (:831): per-block symbol histograms and the enc_speed
+// block policy (deflate.mbt:243-269): kind 0 = stored (<= 16 B tail), 1 = Huffman-only,
+// 2 = dynamic.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void huff_hist_kernel(HuffParams P) {
+  __shared__ SharedHist sh;
+  const int lane = threadIdx.x;
+  const uint32_t sid = blockIdx.x;
+  if (sid >= P.n_streams) return;
+  const BlockGeom g = block_geom(P, sid);
+  for (uint32_t b = 0; b < g.nblocks; ++b) {
+    const uint8_t *src = g.stream + (uint64_t)b * kMaxStoreBlockSize;
+    const int n = b < g.full ? kMaxStoreBlockSize : g.r;
+    const uint32_t gb = g.blk0 + b;
+    int kind;
+    if (n < kSmallLzMin) {
+      kind = n <= 16 ? 0 : 1;
+    } else {
+      kind = P.chunk_ntok[g.chunk0 + b] > (uint32_t)(n - (n >> 4)) ? 1 : 2;  // deflate.mbt:266
+    }
+    if (lane == 0) P.blk_meta[gb] = make_uint4((uint32_t)kind, 0u, 0u, 0u);
+    if (kind == 0) continue;
+    for (int i = lane; i < 288; i += 64) sh.lit_freq[i] = 0;
+    if (lane < 32) sh.off_freq[lane] = 0;
+    __syncthreads();
+    if (kind == 1) {
+      uint32_t nxt = lane < n ? src[lane] : 0u;
+      for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const uint32_t bt = nxt;
+        nxt = i + 64 < n ? src[i + 64] : 0u;
+        if (i < n) atomicAdd(&sh.lit_freq[bt], 1u);
+      }
+      __syncthreads();
+      if (lane == 0) {
+        sh.lit_freq[kEndBlockMarker] = 1;
+        sh.off_freq[0] = 1;
+      }
+    } else {
+      const uint32_t chunk = g.chunk0 + b;
+      Walker w = walker_init(src, P.matches + (uint64_t)chunk * kMatchCapPerChunk, P.chunk_nmatch[chunk],
+                             n, lane);
+      for (int P0 = 0; P0 < n; P0 += 64) {
+        const TileTok t = walk_tile(sh.tile, w, P0, lane);
+        if (t.is_match) {
+          const CodeBits lc = length_code_of((t.tok >> kLengthShift) & 0xffu);
+          const CodeBits oc = offset_code_of(t.tok & ((1u << kLengthShift) - 1u));
+          atomicAdd(&sh.lit_freq[kLengthCodesStart + lc.code], 1u);
+          atomicAdd(&sh.off_freq[oc.code], 1u);
+        } else if (t.is_lit) {
+          atomicAdd(&sh.lit_freq[t.byte], 1u);
+        }
+      }
+      if (lane == 0) atomicAdd(&sh.lit_freq[kEndBlockMarker], 1u);  // tokens.push(EOB), :507
+    }
+    __syncthreads();
+    uint32_t *h = P.blk_hist + (uint64_t)gb * kBlkStride;
+    for (int i = lane; i < 288; i += 64) h[i] = sh.lit_freq[i];
+    if (lane < 32) h[288 + lane] = sh.off_freq[lane];
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Per block: Huffman codes, header items, stored-vs-Huffman decision and the exact bit size,
+// hence every block's start bit inside its stream and the stream's byte length.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void huff_code_kernel(HuffParams P) {
   __shared__ Shared sh;
   const int lane = threadIdx.x;
   const uint32_t sid = blockIdx.x;
   if (sid >= P.n_streams) return;
-
-  const uint64_t a = P.in_off[sid];
-  const uint64_t L = P.in_off[sid + 1] - a;
-  const uint8_t *stream = P.in + a;
-  const uint32_t chunk0 = P.chunk_base[sid];
-
-  for (int i = lane; i < kRing; i += 64) sh.ring[i] = 0;
-#ifdef FLATE_HP_STAMPS
-  if (lane < 8) sh.st[lane] = 0;
-  const uint64_t k0 = __builtin_amdgcn_s_memtime();
-#endif
-  __syncthreads();
-  BitSink S;
-  S.ring = sh.ring;
-  S.out32 = reinterpret_cast<uint32_t *>(P.slots + P.slot_off[sid]);
-  S.bitpos = 0;
-  S.flushed = 0;
-
-  const uint64_t full = L / (uint64_t)kMaxStoreBlockSize;
-  const int r = (int)(L % (uint64_t)kMaxStoreBlockSize);
-  const uint64_t nblocks = full + (r > 0 ? 1 : 0);
-  for (uint64_t b = 0; b < nblocks; ++b) {
-    const uint8_t *src = stream + b * (uint64_t)kMaxStoreBlockSize;
-    const int n = b < full ? kMaxStoreBlockSize : r;
-    if (n < kSmallLzMin) {  // only the tail can be this short (deflate.mbt:243-256)
-      if (n <= 16)
-        emit_stored(S, src, n, false, lane);
-      else
-        block_huff(sh, S, P, src, n, lane);
-      continue;
+  const BlockGeom g = block_geom(P, sid);
+  uint64_t bitpos = 0;
+  for (uint32_t b = 0; b < g.nblocks; ++b) {
+    const int n = b < g.full ? kMaxStoreBlockSize : g.r;
+    const uint32_t gb = g.blk0 + b;
+    int kind = (int)P.blk_meta[gb].x;
+    uint32_t hdr_bits = 0;
+    uint64_t bits = 0;
+    if (kind != 0) {
+      const uint32_t *h = P.blk_hist + (uint64_t)gb * kBlkStride;
+      for (int i = lane; i < 288; i += 64) sh.lit_freq[i] = h[i];
+      if (lane < 32) sh.off_freq[lane] = h[288 + lane];
+      __syncthreads();
+      int num_literals, num_offsets;
+      build_code(sh, sh.lit_freq, kMaxNumLit, 15, sh.lit_cl, lane);
+      if (kind == 1) {  // write_block_huff (:738-776): huff_offset = code 0 of length 1
+        num_literals = kEndBlockMarker + 1;
+        num_offsets = 1;
+        if (lane < 32) sh.off_cl[lane] = lane == 0 ? (1u << 16) : 0u;
+        __syncthreads();
+      } else {  // index_tokens tail (:575-591)
+        uint32_t hi = 0;
+        for (int i = lane; i < kMaxNumLit; i += 64)
+          if (sh.lit_freq[i]) hi = (uint32_t)i + 1;
+        num_literals = (int)wave_max(hi);
+        const uint32_t ho = (lane < kOffsetCodeCount && sh.off_freq[lane]) ? (uint32_t)lane + 1 : 0u;
+        num_offsets = (int)wave_max(ho);
+        if (num_offsets == 0) {
+          if (lane == 0) sh.off_freq[0] = 1;
+          num_offsets = 1;
+        }
+        __syncthreads();
+        build_code(sh, sh.off_freq, kOffsetCodeCount, 15, sh.off_cl, lane);
+      }
+      hdr_bits = make_header(sh, num_literals, num_offsets, lane);
+      uint32_t part = 0, extra = 0;
+      for (int i = lane; i < kMaxNumLit; i += 64) {
+        part += sh.lit_freq[i] * (sh.lit_cl[i] >> 16);
+        if (i >= kLengthCodesStart) extra += sh.lit_freq[i] * len_extra_of_code((uint32_t)(i - kLengthCodesStart));
+      }
+      if (lane < kOffsetCodeCount) {
+        part += sh.off_freq[lane] * (sh.off_cl[lane] >> 16);
+        extra += sh.off_freq[lane] * off_extra_of_code((uint32_t)lane);
+      }
+      if (kind == 1) extra = 0;
+      const uint32_t payload = wave_sum(part);           // what dynamic_size counts (:355-358)
+      const uint32_t extra_bits = wave_sum(extra);        // ... and what it leaves out (:519-523)
+      const uint32_t size = hdr_bits + payload;
+      // In Huffman-only blocks the (unused) offset code still counts 1 bit in `size` but no
+      // offset symbol is ever written.
+      const uint32_t written = kind == 1 ? size - 1u : size + extra_bits;
+      if (prefer_stored(P.compat_go, n, size)) {
+        kind = 0;
+      } else {
+        bits = written;
+        uint32_t *cl = P.blk_cl + (uint64_t)gb * kBlkStride;
+        for (int i = lane; i < 288; i += 64) cl[i] = sh.lit_cl[i];
+        if (lane < 32) cl[288 + lane] = sh.off_cl[lane];
+        uint32_t *hd = P.blk_hdr + (uint64_t)gb * kHdrMax;
+        const int hn = (int)sh.hdr_n;
+        for (int i = lane; i < hn; i += 64) hd[i] = ((uint32_t)sh.hdr_nb[i] << 16) | sh.hdr_val[i];
+      }
     }
-    const uint32_t chunk = chunk0 + (uint32_t)b;
-    const uint32_t ntok = P.chunk_ntok[chunk];
-    if (ntok > (uint32_t)(n - (n >> 4))) {  // deflate.mbt:266
-      block_huff(sh, S, P, src, n, lane);
+    const uint64_t start = bitpos;
+    if (kind == 0) {  // write_stored_header + write_bytes (:474-487,202-225)
+      bitpos = ((bitpos + 3 + 7) & ~7ull) + 32 + 8ull * (uint64_t)n;
     } else {
-      block_dynamic(sh, S, P, src, n, P.matches + (uint64_t)chunk * kMatchCapPerChunk,
-                    P.chunk_nmatch[chunk], lane);
+      bitpos += bits;
     }
+    if (lane == 0)
+      P.blk_meta[gb] = make_uint4((uint32_t)kind, kind ? sh.hdr_n : 0u, (uint32_t)start, (uint32_t)(start >> 32));
+    __syncthreads();
   }
   // Compressor::close: empty stored block with BFINAL, then flush (deflate.mbt:171-176)
-  emit_stored(S, stream, 0, true, lane);
-  sink_finish(S, lane);
-  if (lane == 0) P.out_len[sid] = S.bitpos >> 3;
-#ifdef FLATE_HP_STAMPS
-  if (lane == 0 && P.debug) {
-    sh.st[6] = __builtin_amdgcn_s_memtime() - k0;
-    for (int i = 0; i < 8; ++i) P.debug[(uint64_t)sid * 8 + i] = sh.st[i];
+  bitpos = ((bitpos + 3 + 7) & ~7ull) + 32;
+  if (lane == 0) P.out_len[sid] = bitpos >> 3;
+}
+
+// ---------------------------------------------------------------------------------------
+// write_dynamic_header (:421-471), write_tokens (:596-731), write_block_huff's byte loop
+// (:788-823), stored blocks: the stream's bits go to out + out_off[sid].
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void huff_pack_kernel(HuffParams P) {
+  __shared__ SharedPack sh;
+  const int lane = threadIdx.x;
+  const uint32_t sid = blockIdx.x;
+  if (sid >= P.n_streams || *P.status != 0) return;
+  const BlockGeom g = block_geom(P, sid);
+
+  for (int i = lane; i < kRing; i += 64) sh.ring[i] = 0;
+  __syncthreads();
+  uint8_t *dst = P.out + P.out_off[sid];
+  const uint64_t out_bytes = P.out_len[sid];
+  BitSink S;
+  S.ring = sh.ring;
+  S.head = (uint32_t)((uintptr_t)dst & 3u);
+  S.out32 = reinterpret_cast<uint32_t *>(dst - S.head);
+  S.bitpos = 8ull * S.head;
+  S.flushed = 0;
+  {
+    const uint64_t end_byte = S.head + out_bytes;  // exclusive, relative to out32
+    S.last_dw = (uint32_t)((end_byte - 1) >> 2);
+    S.tail = (uint32_t)(((end_byte - 1) & 3u) + 1u);
   }
-#endif
+  const uint64_t bit0 = S.bitpos;
+
+  for (uint32_t b = 0; b < g.nblocks; ++b) {
+    const uint8_t *src = g.stream + (uint64_t)b * kMaxStoreBlockSize;
+    const int n = b < g.full ? kMaxStoreBlockSize : g.r;
+    const uint32_t gb = g.blk0 + b;
+    const uint4 meta = P.blk_meta[gb];
+    const int kind = (int)meta.x;
+    if (kind == 0) {
+      emit_stored(S, src, n, false, lane);
+      continue;
+    }
+    __syncthreads();
+    const uint32_t *cl = P.blk_cl + (uint64_t)gb * kBlkStride;
+    for (int i = lane; i < 288; i += 64) sh.lit_cl[i] = cl[i];
+    if (lane < 32) sh.off_cl[lane] = cl[288 + lane];
+    __syncthreads();
+    {  // header items written by huff_code_kernel
+      const uint32_t *hd = P.blk_hdr + (uint64_t)gb * kHdrMax;
+      const int hn = (int)meta.y;
+      for (int base = 0; base < hn; base += 64) {
+        const int i = base + lane;
+        const uint32_t it = i < hn ? hd[i] : 0u;
+        sink_emit(S, it & 0xffffu, it >> 16, lane);
+      }
+    }
+    if (kind == 1) {
+      uint32_t nxt = lane < n ? src[lane] : 0u;
+      for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const uint32_t bt = nxt;
+        nxt = i + 64 < n ? src[i + 64] : 0u;
+        const uint32_t c = i < n ? sh.lit_cl[bt] : 0u;
+        sink_emit(S, c & 0xffffu, c >> 16, lane);
+      }
+    } else {
+      const uint32_t chunk = g.chunk0 + b;
+      Walker w = walker_init(src, P.matches + (uint64_t)chunk * kMatchCapPerChunk, P.chunk_nmatch[chunk],
+                             n, lane);
+      for (int P0 = 0; P0 < n; P0 += 64) {
+        const TileTok t = walk_tile(sh.tile, w, P0, lane);
+        uint64_t bits = 0;
+        uint32_t nb = 0;
+        if (t.is_match) {
+          const CodeBits lc = length_code_of((t.tok >> kLengthShift) & 0xffu);
+          const CodeBits oc = offset_code_of(t.tok & ((1u << kLengthShift) - 1u));
+          const uint32_t c1 = sh.lit_cl[kLengthCodesStart + lc.code];
+          const uint32_t c2 = sh.off_cl[oc.code];
+          bits = c1 & 0xffffu;
+          nb = c1 >> 16;
+          bits |= (uint64_t)lc.extra << nb;
+          nb += lc.nextra;
+          bits |= (uint64_t)(c2 & 0xffffu) << nb;
+          nb += c2 >> 16;
+          bits |= (uint64_t)oc.extra << nb;
+          nb += oc.nextra;
+        } else if (t.is_lit) {
+          const uint32_t c = sh.lit_cl[t.byte];
+          bits = c & 0xffffu;
+          nb = c >> 16;
+        }
+        sink_emit(S, bits, nb, lane);
+      }
+    }
+    const uint32_t eob = sh.lit_cl[kEndBlockMarker];
+    sink_emit(S, eob & 0xffffu, lane == 0 ? (eob >> 16) : 0u, lane);
+  }
+  emit_stored(S, g.stream, 0, true, lane);  // Compressor::close (deflate.mbt:171-176)
+  sink_finish(S, lane);
+  // the sizes computed by huff_code_kernel and the bits actually written must agree
+  if (lane == 0 && ((S.bitpos - bit0) >> 3) != out_bytes) atomicExch(P.status, -3);
 }
 
 }  // namespace flate
