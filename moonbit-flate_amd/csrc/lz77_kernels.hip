@@ -268,6 +268,8 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, E *table, const 
     bool sparse = false;
     int scan_base = 0, e_idx = 0;
     bool done = false;
+    uint4 own_pre = make_uint4(0, 0, 0, 0);  // input bytes of the next dense batch, loaded early
+    bool pre_valid = false;
 #ifdef FLATE_LZ_STAMPS
     uint64_t st_load = 0, st_dup = 0, st_ev = 0, st_commit = 0, st_sparse = 0, st_nb = 0, st_ext = 0;
 #endif
@@ -286,10 +288,11 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, E *table, const 
         uint32_t h = 0, old = 0;
         pf_sink ^= pf_val;  // retire the previous batch's look-ahead load
         if (e1) {
-          own = ld128(src + q);
+          own = pre_valid ? own_pre : ld128(src + q);
           h = hash4(own.x);
           old = table[h];
         }
+        pre_valid = false;
         const bool inr = e1 && old != 0 && (A1 - old) <= (uint32_t)kMaxMatchOffset;
         uint4 cb = own;
         if (inr) cb = ld128(g.stream + (old - 1));
@@ -493,10 +496,22 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, E *table, const 
         M |= MF;
         INS |= fast_inserts(VISall);
         STAMP(t3);
+        // the next dense batch starts at s - 1: issue its input load now so that its latency
+        // overlaps the record store and the table commit below
+        if (!done && !sparse) {
+          const int qn = s - 1 + lane;
+          if (qn + 1 <= s_limit) own_pre = ld128(src + qn);
+          pre_valid = true;
+        }
         // match records of this batch, in position order, one coalesced store
         if ((MF >> lane) & 1) acc_len += (uint32_t)tot_self;
         if ((M >> lane) & 1)
-          mout[nm + (uint32_t)__popcll(M & lanes_below(lane))] = make_uint2((uint32_t)q, rec_tok);
+        {
+          // write-once records: non-temporal, so they do not evict the guests' tables from L2
+          unsigned long long *dst = reinterpret_cast<unsigned long long *>(
+              mout + nm + (uint32_t)__popcll(M & lanes_below(lane)));
+          __builtin_nontemporal_store(((unsigned long long)rec_tok << 32) | (uint32_t)q, dst);
+        }
         nm += (uint32_t)__popcll(M);
         // commit: slots of non-DUP lanes already hold their position (speculative write);
         // un-inserted lanes and every DUP lane restore the old value, then the inserted DUP
