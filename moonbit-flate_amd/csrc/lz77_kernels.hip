@@ -310,14 +310,24 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, E *table, const 
         asm volatile("" ::: "memory");
         const bool loser = rb != (A1 & kEMask);
         const uint64_t LM = __ballot(loser);
-        uint64_t DUP = LM;
+        // DUPall: every lane that shares its slot with another lane of the batch (the commit
+        // below must order their writes).  DUP: the lanes whose candidate may be a position
+        // inserted by this batch, i.e. all but the first member of each group -- for the common
+        // two-lane group only the later lane.
+        uint64_t DUPall = LM, DUP = 0;
         if (LM) {
           const int wl = (int)((rb - (W + (uint32_t)B + 1u)) & kEMask);  // lane that owns the slot
           uint64_t m = LM;
           while (m) {
-            const int w = (int)rdlane((uint32_t)wl, __builtin_ctzll(m));
-            DUP |= 1ull << w;
-            m &= ~__ballot(loser && wl == w);
+            const int x = __builtin_ctzll(m);
+            const int w = (int)rdlane((uint32_t)wl, x);
+            const uint64_t Lw = __ballot(loser && wl == w);
+            DUPall |= 1ull << w;
+            if (__popcll(Lw) == 1)
+              DUP |= 1ull << (w > x ? w : x);
+            else
+              DUP |= Lw | (1ull << w);
+            m &= ~Lw;
           }
         }
         STAMP(t1);
@@ -517,8 +527,8 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, E *table, const 
         // un-inserted lanes and every DUP lane restore the old value, then the inserted DUP
         // lanes write in position order so that the latest one wins.
         asm volatile("" ::: "memory");
-        if (e1 && (((DUP | ~INS) >> lane) & 1)) table[h] = (E)old;
-        uint64_t dm = DUP & INS;
+        if (e1 && (((DUPall | ~INS) >> lane) & 1)) table[h] = (E)old;
+        uint64_t dm = DUPall & INS;
         while (dm) {
           const int k = __builtin_ctzll(dm);
           asm volatile("" ::: "memory");
