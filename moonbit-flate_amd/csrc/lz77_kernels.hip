@@ -331,6 +331,13 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, E *table, const 
           }
         }
         STAMP(t1);
+        // probe lanes of the event that would start with s-1 == my lane (independent of the
+        // candidate bytes still in flight)
+        const int bsh = lane + 2;
+        const uint64_t specR = (E1 & (2ull << lane)) | ((0x00000000ffffffffull << bsh) & E1) |
+                               ((0x5555555500000000ull << bsh) & E2);
+        const uint64_t dupR = DUP & specR;
+        const int fd = dupR ? __builtin_ctzll(dupR) : 64;
         const int mlen = inr ? prefix16(own, cb) : 0;
         const uint64_t OK = __ballot(mlen >= 4);
         // per-lane facts about "a match at my position against my slot's old value"
@@ -342,15 +349,9 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, E *table, const 
         // match ends the chunk, bit18 stop chasing (chunk end or next start lane > kDenseKeep),
         // [31:24] lane of the next event start (s-1 of the next event)
         uint32_t ev;
-        uint64_t insm;     // lanes inserted by that event
         {
-          const int bsh = lane + 2;
-          const uint64_t scanR = ((0x00000000ffffffffull << bsh) & E1) |
-                                 ((0x5555555500000000ull << bsh) & E2);
-          const uint64_t R = (E1 & (2ull << lane)) | scanR;
-          const uint64_t okR = OK & R & ~DUP, dupR = DUP & R;
+          const uint64_t okR = OK & specR & ~DUP;
           const int fv = okR ? __builtin_ctzll(okR) : 64;
-          const int fd = dupR ? __builtin_ctzll(dupR) : 64;
           const int tf = __shfl(tot_self, fv & 63);
           const bool slow = !(fv < fd) || tf >= 16;
           const bool ends = B + fv + tf >= s_limit;
@@ -358,7 +359,6 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, E *table, const 
           ev = (uint32_t)(fv & 127) | ((uint32_t)tf << 8) | (slow ? 1u << 16 : 0u) |
                (ends ? 1u << 17 : 0u) | ((ends || nxt > kDenseKeep) ? 1u << 18 : 0u) |
                ((uint32_t)(nxt & 255) << 24);
-          insm = (R & lanes_upto(fv & 63)) | (E1 & (1ull << lane));
         }
         STAMP(t2);
 
