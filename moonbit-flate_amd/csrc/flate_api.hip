@@ -201,8 +201,7 @@ int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, cons
     if ((rc = ensure(c, c->d_queue, 64))) return rc;
     const uint32_t n16 = (uint32_t)pl.ids16.size();
     (void)n16;
-    c->queue_init = 0;
-    HIP_TRY(c, hipMemcpyAsync(c->d_queue.p, &c->queue_init, 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_queue.p, 0, 8, c->stream));
   }
 #ifdef FLATE_LZ_STAMPS
   if ((rc = ensure(c, c->d_debug, (size_t)pl.n_chunks * 64 + 64))) return rc;
@@ -224,33 +223,42 @@ int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, cons
                            c->stream, P);
       }
     } else {
-      if (!pl.ids16.empty()) {
-        P.stream_ids = (const uint32_t *)c->d_ids16.p;
-        const uint32_t n16 = (uint32_t)pl.ids16.size();
-        const bool guests = c->guest_blocks > 0 && n16 >= c->guest_min;
-        if (guests) {
-          // fork: resident (LDS-table) and guest (L2-table) blocks pull streams from one queue
-          LzParams G = P;
-          G.gtables = c->d_gtables.p;
-          G.queue = (uint32_t *)c->d_queue.p;
-          G.queue_end = n16;
-          (void)hipEventRecord(c->ev_fork, c->stream);
-          (void)hipStreamWaitEvent(c->guest_stream, c->ev_fork, 0);
-          hipLaunchKernelGGL(lz77_guest_kernel<uint16_t>, dim3((uint32_t)c->guest_blocks), dim3(64), 0,
+      // single-window streams (ids16) and multi-window streams (ids32) use the same 32 KiB
+      // 16-bit tables; the latter add the periodic sweep (MULTI)
+      auto launch = [&](const DevBuf &ids, uint32_t count, bool multi, uint32_t queue_slot) {
+        if (!count) return;
+        P.stream_ids = (const uint32_t *)ids.p;
+        const bool guests = c->guest_blocks > 0 && count >= c->guest_min;
+        if (!guests) {
+          if (multi)
+            hipLaunchKernelGGL(lz77_wave_kernel<true>, dim3(count), dim3(64), 0, c->stream, P);
+          else
+            hipLaunchKernelGGL(lz77_wave_kernel<false>, dim3(count), dim3(64), 0, c->stream, P);
+          return;
+        }
+        // fork: resident (LDS-table) and guest (L2-table) blocks pull streams from one queue
+        LzParams G = P;
+        G.gtables = c->d_gtables.p;
+        G.queue = (uint32_t *)c->d_queue.p + queue_slot;
+        G.queue_end = count;
+        (void)hipEventRecord(c->ev_fork, c->stream);
+        (void)hipStreamWaitEvent(c->guest_stream, c->ev_fork, 0);
+        const uint32_t resident = c->resident_blocks < count ? c->resident_blocks : count;
+        if (multi) {
+          hipLaunchKernelGGL(lz77_guest_kernel<true>, dim3((uint32_t)c->guest_blocks), dim3(64), 0,
                              c->guest_stream, G);
           (void)hipEventRecord(c->ev_join, c->guest_stream);
-          const uint32_t resident = c->resident_blocks < n16 ? c->resident_blocks : n16;
-          hipLaunchKernelGGL(lz77_wave_kernel<uint16_t>, dim3(resident), dim3(64), 0, c->stream, G);
-          (void)hipStreamWaitEvent(c->stream, c->ev_join, 0);
+          hipLaunchKernelGGL(lz77_wave_kernel<true>, dim3(resident), dim3(64), 0, c->stream, G);
         } else {
-          hipLaunchKernelGGL(lz77_wave_kernel<uint16_t>, dim3(n16), dim3(64), 0, c->stream, P);
+          hipLaunchKernelGGL(lz77_guest_kernel<false>, dim3((uint32_t)c->guest_blocks), dim3(64), 0,
+                             c->guest_stream, G);
+          (void)hipEventRecord(c->ev_join, c->guest_stream);
+          hipLaunchKernelGGL(lz77_wave_kernel<false>, dim3(resident), dim3(64), 0, c->stream, G);
         }
-      }
-      if (!pl.ids32.empty()) {
-        P.stream_ids = (const uint32_t *)c->d_ids32.p;
-        hipLaunchKernelGGL(lz77_wave_kernel<uint32_t>, dim3((uint32_t)pl.ids32.size()), dim3(64),
-                           0, c->stream, P);
-      }
+        (void)hipStreamWaitEvent(c->stream, c->ev_join, 0);
+      };
+      launch(c->d_ids16, (uint32_t)pl.ids16.size(), false, 0);
+      launch(c->d_ids32, (uint32_t)pl.ids32.size(), true, 1);
     }
   }
   HIP_TRY(c, hipGetLastError());

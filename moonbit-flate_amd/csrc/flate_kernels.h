@@ -70,9 +70,9 @@ struct InfParams {
 };
 
 __global__ void lz77_serial_kernel(LzParams P);
-template <typename E>
+template <bool MULTI>
 __global__ void lz77_wave_kernel(LzParams P);
-template <typename E>
+template <bool MULTI>
 __global__ void lz77_guest_kernel(LzParams P);
 __global__ void huff_hist_kernel(HuffParams P);
 __global__ void huff_code_kernel(HuffParams P);

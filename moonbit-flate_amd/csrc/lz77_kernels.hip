@@ -239,16 +239,41 @@ FLATE_D int extend_match(const uint8_t *src, const uint8_t *stream, uint32_t W, 
 
 // One stream, start to finish.  `table` is the 16384-slot position table of this stream: LDS for
 // the resident kernel, a per-block slice of HBM (L2-resident) for the guest kernel.
-template <typename E>
-FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, E *table, const int lane) {
+// Table slots are 16 bits.  MULTI == false (the stream has one LZ77 window): slot = position + 1,
+// 0 = empty.  MULTI == true (windows chained through the table, deflate-fast.mbt:156,193): slot =
+// (absolute position + 1) mod 2^16 and the distance is taken mod 2^16; that is unambiguous because
+// every kSweepEvery positions the table is swept and every slot older than 32768 (dead for the
+// reference too, :195) is replaced by a marker that stays out of range until the next sweep, and
+// because a sparse batch never spans more than kSpanMax positions.
+constexpr uint32_t kSweepEvery = 8192, kSpanMax = 16384, kMarkerBack = 36864;
+
+template <bool MULTI>
+FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table, const int lane) {
+  using E = uint16_t;
   {
     uint4 *t4 = reinterpret_cast<uint4 *>(table);
-    const uint4 z = make_uint4(0, 0, 0, 0);
+    const uint32_t fill = MULTI ? (((0u - kMarkerBack + 1u) & 0xffffu) * 0x10001u) : 0u;
+    const uint4 z = make_uint4(fill, fill, fill, fill);
     for (int i = lane; i < (int)(kTableSize * sizeof(E) / 16); i += 64) t4[i] = z;
   }
   __syncthreads();
   volatile E *vtable = table;
-  constexpr uint32_t kEMask = sizeof(E) == 2 ? 0xffffu : 0xffffffffu;
+  constexpr uint32_t kEMask = 0xffffu;
+  uint32_t next_sweep = kSweepEvery;  // MULTI: absolute position at which the next sweep is due
+  // Sweep: slots whose position is more than 32768 behind R can never be candidates again.
+  auto sweep = [&](uint32_t R) {
+    uint32_t *t32 = reinterpret_cast<uint32_t *>(table);
+    const uint32_t marker = (R - kMarkerBack + 1u) & 0xffffu;
+    for (int i = lane; i < kTableSize / 2; i += 64) {
+      const uint32_t v = t32[i];
+      const uint32_t d0 = (R + 1u - v) & 0xffffu, d1 = (R + 1u - (v >> 16)) & 0xffffu;
+      const uint32_t lo = (d0 == 0 || d0 > 32768u) ? marker : (v & 0xffffu);
+      const uint32_t hi = (d1 == 0 || d1 > 32768u) ? marker : (v >> 16);
+      t32[i] = lo | (hi << 16);
+    }
+    __syncthreads();
+    next_sweep = R + kSweepEvery;
+  };
 
   const ChunkGeom g = stream_geom(P, sid);
   const uint16_t *scan_tab = P.scan_off;
@@ -279,6 +304,10 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, E *table, const 
         // =============================== dense batch ===============================
         STAMP(t0);
         const int B = s - 1;
+        if (MULTI) {
+          const uint32_t first = W + (uint32_t)(B < 0 ? 0 : B);
+          if (first >= next_sweep) sweep(first);
+        }
         const int q = B + lane;
         const bool e1 = q >= 0 && q + 1 <= s_limit;  // may be inserted / probed with step 1
         const bool e2 = q >= 0 && q + 2 <= s_limit;  // may be probed with step 2
@@ -293,9 +322,12 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, E *table, const 
           old = table[h];
         }
         pre_valid = false;
-        const bool inr = e1 && old != 0 && (A1 - old) <= (uint32_t)kMaxMatchOffset;
+        // candidate = absolute position stored in my slot; valid if within 32768 (:195)
+        const uint32_t dist = MULTI ? ((A1 - old) & 0xffffu) : (A1 - old);
+        const bool inr = e1 && (MULTI ? dist != 0 : old != 0) && dist <= (uint32_t)kMaxMatchOffset;
+        const uint32_t cand_abs = A1 - 1u - dist;
         uint4 cb = own;
-        if (inr) cb = ld128(g.stream + (old - 1));
+        if (inr) cb = ld128(g.stream + cand_abs);
         {  // look-ahead: pull the next lines of this stream towards L2.  Issued after the
            // candidate gather so that no wait of this batch has to include it.
           int pq = B + 768 + 4 * lane;
@@ -341,9 +373,9 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, E *table, const 
         const int mlen = inr ? prefix16(own, cb) : 0;
         const uint64_t OK = __ballot(mlen >= 4);
         // per-lane facts about "a match at my position against my slot's old value"
-        const bool cross = !P.compat_go && old + 3 < W;         // (old-1)+4 < W: MoonBit prev is empty
+        const bool cross = MULTI && !P.compat_go && cand_abs + 4 < W;  // MoonBit: prev window is empty
         const int tot_self = cross ? 4 : mlen;                   // 16 => needs extension (slow)
-        uint32_t rec_tok = kMatchType | ((uint32_t)(tot_self - 3) << kLengthShift) | (A1 - old - 1);
+        uint32_t rec_tok = kMatchType | ((uint32_t)(tot_self - 3) << kLengthShift) | (dist - 1u);
         // speculative evaluation of the event that would start with s-1 == my lane
         // ev: [6:0] match lane fv, [15:8] total length, bit16 general path needed, bit17 the
         // match ends the chunk, bit18 stop chasing (chunk end or next start lane > kDenseKeep),
@@ -428,7 +460,7 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, E *table, const 
             const int fv = ffs64(OK & rem & ~DUP), fd = ffs64(DUP & rem);
             if (fv < fd) {
               f = fv;
-              cand = rdlane(old, fv) - 1;
+              cand = rdlane(cand_abs, fv);
               have = (int)rdlane((uint32_t)mlen, fv);
               T |= rem & lanes_upto(fv);
               break;
@@ -456,7 +488,7 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, E *table, const 
               ml = prefix16(of, oi);
             } else {
               v = (OK >> fd) & 1;
-              cnd = rdlane(old, fd) - 1;
+              cnd = rdlane(cand_abs, fd);
               ml = (int)rdlane((uint32_t)mlen, fd);
             }
             T |= 1ull << fd;
@@ -556,9 +588,14 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, E *table, const 
           p = scan_base + o0 + (e - ec) * 65536;  // beyond the table => never exists
           step = o1 - o0;
         }
-        const bool exists = p + step <= s_limit;  // the `next_s > s_limit` test of :188
+        const bool exists_all = p + step <= s_limit;  // the `next_s > s_limit` test of :188
+        const int p0 = (int)rdlane((uint32_t)p, 0);
+        // MULTI: keep the batch within kSpanMax positions (the later probes move to the next batch)
+        const bool exists = exists_all && (!MULTI || (uint32_t)(p - p0) < kSpanMax);
+        const int nall = __popcll(__ballot(exists_all));
         const int nexist = __popcll(__ballot(exists));  // events are a prefix of the lanes
-        if (nexist == 0) break;                         // emit_remainder (:152-159)
+        if (nall == 0) break;                           // emit_remainder (:152-159)
+        if (MULTI && W + (uint32_t)p0 >= next_sweep) sweep(W + (uint32_t)p0);
 
         uint32_t cv = 0, h = 0, old = 0;
         if (exists) {
@@ -567,9 +604,11 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, E *table, const 
           old = vtable[h];
         }
         const uint32_t A1 = W + (uint32_t)p + 1;
+        const uint32_t dist = MULTI ? ((A1 - old) & 0xffffu) : (A1 - old);
+        const uint32_t cand_abs = A1 - 1u - dist;
         bool ok = false;
-        if (exists && old != 0 && (A1 - old) <= (uint32_t)kMaxMatchOffset)
-          ok = ld32(g.stream + (old - 1)) == cv;
+        if (exists && (MULTI ? dist != 0 : old != 0) && dist <= (uint32_t)kMaxMatchOffset)
+          ok = ld32(g.stream + cand_abs) == cv;
         const uint64_t V = __ballot(ok);
         const int f0 = ffs64(V);
 
@@ -581,9 +620,9 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, E *table, const 
         const uint64_t C = __ballot(rb != (A1 & kEMask));
 
         int f = f0;
-        uint32_t cand1 = 0;  // candidate position + 1
+        uint32_t cand = 0;  // absolute candidate position
         if (C == 0) {
-          if (f0 < 64) cand1 = rdlane(old, f0);
+          if (f0 < 64) cand = rdlane(cand_abs, f0);
         } else {
           // two lanes of this batch share a slot: replay the batch in order
           if (ins) vtable[h] = (E)old;
@@ -595,28 +634,33 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, E *table, const 
                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)vtable[he]);
             vtable[he] = (E)pe1;
             bool v;
+            uint32_t cnd;
             if (cur == rdlane(old, e2)) {
               v = (V >> e2) & 1;
+              cnd = rdlane(cand_abs, e2);
             } else {  // candidate was inserted by an earlier lane of this batch
               const uint64_t m = __ballot(exists && (A1 & kEMask) == cur);
               v = false;
-              if (m) v = rdlane(cv, __builtin_ctzll(m)) == rdlane(cv, e2);
+              cnd = 0;
+              if (m) {
+                const int i = __builtin_ctzll(m);
+                v = rdlane(cv, i) == rdlane(cv, e2);
+                cnd = rdlane(A1, i) - 1u;
+              }
             }
             if (v) {
               f = e2;
-              cand1 = cur;
+              cand = cnd;
               break;
             }
           }
         }
         if (f == 64) {
-          if (nexist < 64) break;
-          e_idx += 64;
+          if (nexist == nall && nall < 64) break;  // the scan ran into s_limit
+          e_idx += nexist;
           continue;
         }
         const int pf = (int)rdlane((uint32_t)p, f);
-        uint32_t cand = cand1 - 1;
-        if (sizeof(E) == 2) cand &= 0xffffu;
         const int total = extend_match(src, g.stream, W, n, pf, cand, 4, P.compat_go, lane);
         if (lane == 0)
           mout[nm] = make_uint2((uint32_t)pf, kMatchType | ((uint32_t)(total - 3) << kLengthShift) |
@@ -645,14 +689,14 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, E *table, const 
   }
 }
 
-// Resident kernel: table in LDS (32 or 64 KiB per stream => 5 or 2 streams per CU).
-template <typename E>
+// Resident kernel: table in LDS (32 KiB per stream => 5 streams per CU).
+template <bool MULTI>
 __global__ __launch_bounds__(64) void lz77_wave_kernel(LzParams P) {
-  __shared__ E table[kTableSize];
+  __shared__ uint16_t table[kTableSize];
   const int lane = threadIdx.x;
   if (!P.queue) {  // one block per stream
     const uint32_t sid = P.stream_ids ? P.stream_ids[blockIdx.x] : blockIdx.x;
-    lz77_stream<E>(P, sid, table, lane);
+    lz77_stream<MULTI>(P, sid, table, lane);
     return;
   }
   for (;;) {  // persistent: resident and guest blocks share one queue (dynamic balance)
@@ -661,7 +705,7 @@ __global__ __launch_bounds__(64) void lz77_wave_kernel(LzParams P) {
     q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
     if (q >= P.queue_end) break;
     __syncthreads();
-    lz77_stream<E>(P, P.stream_ids[q], table, lane);
+    lz77_stream<MULTI>(P, P.stream_ids[q], table, lane);
     __syncthreads();
   }
 }
@@ -670,9 +714,9 @@ __global__ __launch_bounds__(64) void lz77_wave_kernel(LzParams P) {
 // (the parser is latency-bound).  A small persistent grid of extra wavefronts runs the same
 // parser with tables in HBM scratch -- few enough that those tables stay in the 4 MiB L2 of
 // their XCD -- and pulls streams from a queue.
-template <typename E>
+template <bool MULTI>
 __global__ __launch_bounds__(64) void lz77_guest_kernel(LzParams P) {
-  E *table = reinterpret_cast<E *>(P.gtables) + (size_t)blockIdx.x * kTableSize;
+  uint16_t *table = reinterpret_cast<uint16_t *>(P.gtables) + (size_t)blockIdx.x * kTableSize;
   const int lane = threadIdx.x;
   for (;;) {
     uint32_t q = 0;
@@ -680,13 +724,14 @@ __global__ __launch_bounds__(64) void lz77_guest_kernel(LzParams P) {
     q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
     if (q >= P.queue_end) break;
     __syncthreads();
-    lz77_stream<E>(P, P.stream_ids[q], table, lane);
+    lz77_stream<MULTI>(P, P.stream_ids[q], table, lane);
     __syncthreads();
   }
 }
 
-template __global__ void lz77_wave_kernel<uint16_t>(LzParams);
-template __global__ void lz77_wave_kernel<uint32_t>(LzParams);
-template __global__ void lz77_guest_kernel<uint16_t>(LzParams);
+template __global__ void lz77_wave_kernel<false>(LzParams);
+template __global__ void lz77_wave_kernel<true>(LzParams);
+template __global__ void lz77_guest_kernel<false>(LzParams);
+template __global__ void lz77_guest_kernel<true>(LzParams);
 
 }  // namespace flate

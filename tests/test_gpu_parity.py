@@ -27,6 +27,9 @@ MULTI_WINDOW = [
     ("text", 65537 + 200), ("text", 131072), ("ramp", 131072), ("period", 262144),
     ("runs", 200000), ("zero", 140000), ("low", 131070), ("rand", 70000), ("text", 196605),
     ("text", 65535 * 2 + 127), ("text", 65535 * 2 + 128),
+    # long streams: 16-bit table positions wrap many times (periodic sweeps), sparse scans are
+    # cut at kSpanMax inside incompressible stretches
+    ("text", 1 << 21), ("period", 1500000), ("rand", 300000), ("runs", 700000),
 ]
 
 
@@ -165,3 +168,40 @@ def test_batch_1k_streams_full_size(eng, oracle):
         a = out[int(out_off[i]):int(out_off[i + 1])]
         b = o_out[int(o_off[i]):int(o_off[i]) + int(o_len[i])]
         assert a.size == b.size and np.array_equal(a, b), i
+
+
+def test_full_size_config2_round_trip_property(eng, oracle):
+    # BASELINE configs[1] at full size: 16384 x 64 KiB.  Size-independent properties: every stream
+    # inflates back to its input (GPU inflater, itself oracle-checked), ends with the final empty
+    # stored block, and a strided sample is byte-identical to the oracle.
+    import torch
+    n, blen = 16384, 65536
+    host = flate.synth("text", n, blen)
+    off = flate.uniform_offsets(n, blen)
+    d = torch.from_numpy(host).cuda()
+    comp, coff = eng.deflate_batch(d, off, out_cap=n * blen)
+    back, _, olen, status, _ = eng.inflate_batch(comp, coff, [blen] * n)
+    assert (status == 0).all() and (olen == blen).all()
+    assert torch.equal(back[:n * blen], d)
+    c = comp[:int(coff[-1])].cpu().numpy()
+    ends = coff[1:].astype(np.int64)
+    tail = np.stack([c[ends - 5 + k] for k in range(5)], axis=1)
+    assert (tail == np.array([1, 0, 0, 0xFF, 0xFF], dtype=np.uint8)).all()
+    for i in range(0, n, 257):
+        assert bytes(c[int(coff[i]):int(coff[i + 1])]) == oracle.deflate(host[i * blen:(i + 1) * blen]), i
+
+
+def test_full_size_config3_multi_window(eng, oracle):
+    # BASELINE configs[2]: 256 KiB streams (4 chained windows each); 1024 of them byte-exact vs the
+    # oracle sample + full round trip.
+    import torch
+    n, blen = 1024, 262144
+    host = flate.synth("text", n, blen)
+    off = flate.uniform_offsets(n, blen)
+    d = torch.from_numpy(host).cuda()
+    comp, coff = eng.deflate_batch(d, off, out_cap=n * blen)
+    back, _, olen, status, _ = eng.inflate_batch(comp, coff, [blen] * n)
+    assert (status == 0).all() and torch.equal(back[:n * blen], d)
+    c = comp[:int(coff[-1])].cpu().numpy()
+    for i in range(0, n, 61):
+        assert bytes(c[int(coff[i]):int(coff[i + 1])]) == oracle.deflate(host[i * blen:(i + 1) * blen]), i
