@@ -172,7 +172,7 @@ __global__ __launch_bounds__(64) void lz77_serial_kernel(LzParams P) {
 // SPARSE is served by one probe event per lane (strides grow with the skip counter).
 // tests/host_model/lz77_wave_model.cpp is the lane-accurate CPU model of this kernel.
 // ---------------------------------------------------------------------------------
-constexpr int kDenseKeep = 46;  // keep using a dense batch while the next s-1 lane <= this
+constexpr int kDenseKeep = 58;  // keep using a dense batch while the next s-1 lane <= this
 
 // Diagnostic build only (-DFLATE_LZ_STAMPS): per-chunk s_memtime sums of the batch phases.
 #ifdef FLATE_LZ_STAMPS
@@ -365,9 +365,11 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
         STAMP(t1);
         // probe lanes of the event that would start with s-1 == my lane (independent of the
         // candidate bytes still in flight)
-        const int bsh = lane + 2;
-        const uint64_t specR = (E1 & (2ull << lane)) | ((0x00000000ffffffffull << bsh) & E1) |
-                               ((0x5555555500000000ull << bsh) & E2);
+        const int bsh = lane + 2;  // (lanes 62, 63 have no scan lanes left: shift counts stay < 64)
+        const uint64_t specR = (E1 & (2ull << lane)) |
+                               (bsh < 64 ? (((0x00000000ffffffffull << bsh) & E1) |
+                                            ((0x5555555500000000ull << bsh) & E2))
+                                         : 0ull);
         const uint64_t dupR = DUP & specR;
         const int fd = dupR ? __builtin_ctzll(dupR) : 64;
         const int mlen = inr ? prefix16(own, cb) : 0;
