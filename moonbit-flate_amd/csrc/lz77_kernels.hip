@@ -696,18 +696,21 @@ template <bool MULTI>
 __global__ __launch_bounds__(64) void lz77_wave_kernel(LzParams P) {
   __shared__ uint16_t table[kTableSize];
   const int lane = threadIdx.x;
-  if (!P.queue) {  // one block per stream
-    const uint32_t sid = P.stream_ids ? P.stream_ids[blockIdx.x] : blockIdx.x;
-    lz77_stream<MULTI>(P, sid, table, lane);
-    return;
-  }
-  for (;;) {  // persistent: resident and guest blocks share one queue (dynamic balance)
-    uint32_t q = 0;
-    if (lane == 0) q = atomicAdd(P.queue, 1u);
-    q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
-    if (q >= P.queue_end) break;
+  // Either one block per stream (P.queue == null) or persistent: resident and guest blocks
+  // share one queue (dynamic balance).  One call site keeps a single copy of the parser.
+  for (bool first = true;; first = false) {
+    uint32_t q;
+    if (P.queue) {
+      q = 0;
+      if (lane == 0) q = atomicAdd(P.queue, 1u);
+      q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
+      if (q >= P.queue_end) break;
+    } else {
+      if (!first) break;
+      q = blockIdx.x;
+    }
     __syncthreads();
-    lz77_stream<MULTI>(P, P.stream_ids[q], table, lane);
+    lz77_stream<MULTI>(P, P.stream_ids ? P.stream_ids[q] : q, table, lane);
     __syncthreads();
   }
 }
