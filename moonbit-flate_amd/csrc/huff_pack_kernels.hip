@@ -31,7 +31,8 @@ namespace flate {
 
 namespace {
 
-constexpr int kRing = 256;  // dwords in the LDS bit ring (a tile adds <= 96 dwords)
+constexpr int kRing = 512;  // dwords in the LDS bit ring (a 256-position tile adds <= 186 dwords)
+constexpr int kTile = 256;  // input positions per walk step: 4 consecutive positions per lane
 constexpr int kHdrMax = 704;
 
 #ifdef FLATE_HP_STAMPS
@@ -75,14 +76,14 @@ struct Shared {
 struct SharedHist {
   uint32_t lit_freq[288];
   uint32_t off_freq[32];
-  uint2 tile[64];  // per-tile scatter target: {token starting here, coverage mark +1/-1}
+  uint2 tile[kTile];  // per-tile scatter target: {token starting here, coverage mark +1/-1}
 };
 
 // LDS of huff_pack_kernel
 struct SharedPack {
   uint32_t lit_cl[288];
   uint32_t off_cl[32];
-  uint2 tile[64];
+  uint2 tile[kTile];
   uint32_t ring[kRing];
 };
 
@@ -164,6 +165,44 @@ FLATE_D void sink_emit(BitSink &S, uint64_t bits, uint32_t nb, int lane) {
     S.flushed += 64;
   }
   __syncthreads();
+}
+
+// Wide form: every lane appends nb (<= 96) bits held in (lo, hi), in lane order.
+FLATE_D void sink_emit_wide(BitSink &S, uint64_t lo, uint64_t hi, uint32_t nb, int lane) {
+  const uint32_t incl = wave_incl_scan(nb);
+  const uint32_t total = rdlane(incl, 63);
+  if (nb) {
+    const uint64_t q = S.bitpos + (incl - nb);
+    const uint32_t w = (uint32_t)(q >> 5);
+    const uint32_t sh = (uint32_t)q & 31u;
+    const uint64_t v0 = lo << sh;
+    const uint64_t v1 = (hi << sh) | (sh ? (lo >> (64u - sh)) : 0ull);
+    const uint32_t d0 = (uint32_t)v0, d1 = (uint32_t)(v0 >> 32), d2 = (uint32_t)v1, d3 = (uint32_t)(v1 >> 32);
+    if (d0) atomicOr(&S.ring[w & (kRing - 1)], d0);
+    if (d1) atomicOr(&S.ring[(w + 1) & (kRing - 1)], d1);
+    if (d2) atomicOr(&S.ring[(w + 2) & (kRing - 1)], d2);
+    if (d3) atomicOr(&S.ring[(w + 3) & (kRing - 1)], d3);
+  }
+  S.bitpos += total;
+  __syncthreads();
+  while ((uint32_t)(S.bitpos >> 5) - S.flushed >= 64u) {
+    const uint32_t idx = S.flushed + (uint32_t)lane;
+    sink_store(S, idx, S.ring[idx & (kRing - 1)]);
+    S.ring[idx & (kRing - 1)] = 0;
+    S.flushed += 64;
+  }
+  __syncthreads();
+}
+
+// append nb bits to the (lo, hi) accumulator holding n bits so far
+FLATE_D void acc_append(uint64_t &lo, uint64_t &hi, uint32_t &n, uint64_t bits, uint32_t nb) {
+  if (n < 64u) {
+    lo |= bits << n;
+    if (n && n + nb > 64u) hi |= bits >> (64u - n);
+  } else {
+    hi |= bits << (n - 64u);
+  }
+  n += nb;
 }
 
 // flush(): pad with zero bits to a byte boundary (huffman-bit-writer.mbt:139-158)
@@ -348,11 +387,13 @@ FLATE_D void build_code(Shared &sh, const uint32_t *freq, int nsym, int max_bits
 }
 
 // ---- tile walk over the implied token sequence ----------------------------------------
+// A tile is 256 consecutive input positions; lane L owns positions P0 + 4L .. P0 + 4L + 3.
+// At most one match can start inside a lane's four positions (matches are >= 4 long).
 struct TileTok {
-  bool is_lit;    // this lane's position is a literal
-  bool is_match;  // this lane's position starts a match
-  uint32_t byte;
-  uint32_t tok;
+  uint32_t bytes;     // the lane's four input bytes (little endian)
+  uint32_t lit_mask;  // bit k: position k is a literal
+  int match_k;        // 0..3: a match starts at position k; -1: none
+  uint32_t tok;       // its token
 };
 
 struct Walker {
@@ -363,16 +404,26 @@ struct Walker {
   uint32_t mp;         // next match record
   uint32_t cov_until;  // positions < cov_until are covered by an earlier match
   // software pipeline: data of the tile about to be processed, loaded one tile ahead
-  uint2 rec;           // lanes 0..31: recs[mp + lane]
-  uint32_t byte;       // src[P0 + lane]
+  uint2 rec;           // recs[mp + lane]  (<= 64 matches start in a tile)
+  uint32_t bytes;      // src[P0 + 4 lane .. +3]
 };
 
 FLATE_D uint2 load_rec(const Walker &w, uint32_t mp, int lane) {
   uint2 r = make_uint2(0xffffffffu, 0);
-  if (lane < 32 && mp + (uint32_t)lane < w.nm) r = w.recs[mp + lane];
+  if (mp + (uint32_t)lane < w.nm) r = w.recs[mp + lane];
   return r;
 }
-FLATE_D uint32_t load_byte(const Walker &w, int pos) { return pos < w.n ? w.src[pos] : 0u; }
+FLATE_D uint32_t load_bytes4(const Walker &w, int pos) {
+  if (pos + 4 <= w.n) {
+    uint32_t v;
+    __builtin_memcpy(&v, w.src + pos, 4);
+    return v;
+  }
+  uint32_t v = 0;  // chunk tail: never read past the chunk
+  for (int k = 0; k < 4; ++k)
+    if (pos + k < w.n) v |= (uint32_t)w.src[pos + k] << (8 * k);
+  return v;
+}
 
 FLATE_D Walker walker_init(const uint8_t *src, const uint2 *recs, uint32_t nm, int n, int lane) {
   Walker w;
@@ -383,42 +434,57 @@ FLATE_D Walker walker_init(const uint8_t *src, const uint2 *recs, uint32_t nm, i
   w.mp = 0;
   w.cov_until = 0;
   w.rec = load_rec(w, 0, lane);
-  w.byte = load_byte(w, lane);
+  w.bytes = load_bytes4(w, 4 * lane);
   return w;
 }
 
 FLATE_D TileTok walk_tile(uint2 *tile, Walker &w, int P0, int lane) {
   TileTok t;
-  const int pos = P0 + lane;
+  const int pos = P0 + 4 * lane;
   const uint2 rec = w.rec;
-  const uint32_t byte = w.byte;
-  const bool mine = rec.x < (uint32_t)(P0 + 64);  // <= 16 matches start in a tile (lanes 0..15)
+  t.bytes = w.bytes;
+  const bool mine = rec.x < (uint32_t)(P0 + kTile);
   const int cnt = __popcll(__ballot(mine));
   // issue the next tile's loads now; they are consumed one iteration later
   w.mp += (uint32_t)cnt;
   w.rec = load_rec(w, w.mp, lane);
-  w.byte = load_byte(w, pos + 64);
+  w.bytes = load_bytes4(w, pos + kTile);
   // scatter the tile's matches: token at its start position, +1 at the first covered
   // position, -1 just past the match; a prefix sum of the marks is the coverage
-  tile[lane] = make_uint2(0u, 0u);
+  uint4 *t4 = reinterpret_cast<uint4 *>(tile + 4 * lane);
+  t4[0] = make_uint4(0, 0, 0, 0);
+  t4[1] = make_uint4(0, 0, 0, 0);
   __syncthreads();
   const uint32_t mlen = ((rec.y >> kLengthShift) & 0xffu) + 3u;
   if (mine) {
     const uint32_t o = rec.x - (uint32_t)P0;
     tile[o].x = rec.y;
-    if (o + 1 < 64u) tile[o + 1].y = 1u;
-    if (o + mlen < 64u) tile[o + mlen].y = 0xffffffffu;
+    if (o + 1 < (uint32_t)kTile) tile[o + 1].y = 1u;
+    if (o + mlen < (uint32_t)kTile) tile[o + mlen].y = 0xffffffffu;
   }
   __syncthreads();
-  const uint2 tl = tile[lane];
-  const uint32_t cover = wave_incl_scan(tl.y);
-  const bool covered = (uint32_t)pos < w.cov_until || cover != 0;
+  const uint4 a = t4[0], b = t4[1];  // {tok0, mark0, tok1, mark1}, {tok2, mark2, tok3, mark3}
+  const uint32_t c0 = a.y, c1 = c0 + a.w, c2 = c1 + b.y, c3 = c2 + b.w;
+  const uint32_t base = wave_incl_scan(c3) - c3;  // coverage entering this lane
+  const uint32_t cu = w.cov_until;
   if (cnt) w.cov_until = rdlane(rec.x, cnt - 1) + rdlane(mlen, cnt - 1);
-  const bool active = pos < w.n;
-  t.byte = byte;
-  t.tok = tl.x;
-  t.is_match = active && tl.x != 0;
-  t.is_lit = active && !covered && tl.x == 0;
+  const uint32_t toks[4] = {a.x, a.z, b.x, b.z};
+  const uint32_t cov[4] = {base + c0, base + c1, base + c2, base + c3};
+  t.lit_mask = 0;
+  t.match_k = -1;
+  t.tok = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int pk = pos + k;
+    const bool active = pk < w.n;
+    const bool covered = (uint32_t)pk < cu || cov[k] != 0;
+    if (active && toks[k] != 0) {
+      t.match_k = k;
+      t.tok = toks[k];
+    } else if (active && !covered) {
+      t.lit_mask |= 1u << k;
+    }
+  }
   return t;
 }
 
@@ -591,12 +657,14 @@ __global__ __launch_bounds__(64) void huff_hist_kernel(HuffParams P) {
     if (lane < 32) sh.off_freq[lane] = 0;
     __syncthreads();
     if (kind == 1) {
-      uint32_t nxt = lane < n ? src[lane] : 0u;
-      for (int base = 0; base < n; base += 64) {
-        const int i = base + lane;
-        const uint32_t bt = nxt;
-        nxt = i + 64 < n ? src[i + 64] : 0u;
-        if (i < n) atomicAdd(&sh.lit_freq[bt], 1u);
+      Walker w = walker_init(src, nullptr, 0u, n, lane);
+      for (int base = 0; base < n; base += kTile) {
+        const int i = base + 4 * lane;
+        const uint32_t bt = w.bytes;
+        w.bytes = load_bytes4(w, i + kTile);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (i + k < n) atomicAdd(&sh.lit_freq[(bt >> (8 * k)) & 0xffu], 1u);
       }
       __syncthreads();
       if (lane == 0) {
@@ -607,16 +675,17 @@ __global__ __launch_bounds__(64) void huff_hist_kernel(HuffParams P) {
       const uint32_t chunk = g.chunk0 + b;
       Walker w = walker_init(src, P.matches + (uint64_t)chunk * kMatchCapPerChunk, P.chunk_nmatch[chunk],
                              n, lane);
-      for (int P0 = 0; P0 < n; P0 += 64) {
+      for (int P0 = 0; P0 < n; P0 += kTile) {
         const TileTok t = walk_tile(sh.tile, w, P0, lane);
-        if (t.is_match) {
+        if (t.match_k >= 0) {
           const CodeBits lc = length_code_of((t.tok >> kLengthShift) & 0xffu);
           const CodeBits oc = offset_code_of(t.tok & ((1u << kLengthShift) - 1u));
           atomicAdd(&sh.lit_freq[kLengthCodesStart + lc.code], 1u);
           atomicAdd(&sh.off_freq[oc.code], 1u);
-        } else if (t.is_lit) {
-          atomicAdd(&sh.lit_freq[t.byte], 1u);
         }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if ((t.lit_mask >> k) & 1u) atomicAdd(&sh.lit_freq[(t.bytes >> (8 * k)) & 0xffu], 1u);
       }
       if (lane == 0) atomicAdd(&sh.lit_freq[kEndBlockMarker], 1u);  // tokens.push(EOB), :507
     }
@@ -768,41 +837,51 @@ __global__ __launch_bounds__(64) void huff_pack_kernel(HuffParams P) {
       }
     }
     if (kind == 1) {
-      uint32_t nxt = lane < n ? src[lane] : 0u;
-      for (int base = 0; base < n; base += 64) {
-        const int i = base + lane;
-        const uint32_t bt = nxt;
-        nxt = i + 64 < n ? src[i + 64] : 0u;
-        const uint32_t c = i < n ? sh.lit_cl[bt] : 0u;
-        sink_emit(S, c & 0xffffu, c >> 16, lane);
+      Walker w = walker_init(src, nullptr, 0u, n, lane);
+      for (int base = 0; base < n; base += kTile) {
+        const int i = base + 4 * lane;
+        const uint32_t bt = w.bytes;
+        w.bytes = load_bytes4(w, i + kTile);
+        uint64_t lo = 0, hi = 0;
+        uint32_t nb = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (i + k < n) {
+            const uint32_t c = sh.lit_cl[(bt >> (8 * k)) & 0xffu];
+            acc_append(lo, hi, nb, c & 0xffffu, c >> 16);
+          }
+        sink_emit_wide(S, lo, hi, nb, lane);
       }
     } else {
       const uint32_t chunk = g.chunk0 + b;
       Walker w = walker_init(src, P.matches + (uint64_t)chunk * kMatchCapPerChunk, P.chunk_nmatch[chunk],
                              n, lane);
-      for (int P0 = 0; P0 < n; P0 += 64) {
+      for (int P0 = 0; P0 < n; P0 += kTile) {
         const TileTok t = walk_tile(sh.tile, w, P0, lane);
-        uint64_t bits = 0;
+        uint64_t lo = 0, hi = 0;
         uint32_t nb = 0;
-        if (t.is_match) {
-          const CodeBits lc = length_code_of((t.tok >> kLengthShift) & 0xffu);
-          const CodeBits oc = offset_code_of(t.tok & ((1u << kLengthShift) - 1u));
-          const uint32_t c1 = sh.lit_cl[kLengthCodesStart + lc.code];
-          const uint32_t c2 = sh.off_cl[oc.code];
-          bits = c1 & 0xffffu;
-          nb = c1 >> 16;
-          bits |= (uint64_t)lc.extra << nb;
-          nb += lc.nextra;
-          bits |= (uint64_t)(c2 & 0xffffu) << nb;
-          nb += c2 >> 16;
-          bits |= (uint64_t)oc.extra << nb;
-          nb += oc.nextra;
-        } else if (t.is_lit) {
-          const uint32_t c = sh.lit_cl[t.byte];
-          bits = c & 0xffffu;
-          nb = c >> 16;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if ((t.lit_mask >> k) & 1u) {
+            const uint32_t c = sh.lit_cl[(t.bytes >> (8 * k)) & 0xffu];
+            acc_append(lo, hi, nb, c & 0xffffu, c >> 16);
+          } else if (t.match_k == k) {
+            const CodeBits lc = length_code_of((t.tok >> kLengthShift) & 0xffu);
+            const CodeBits oc = offset_code_of(t.tok & ((1u << kLengthShift) - 1u));
+            const uint32_t c1 = sh.lit_cl[kLengthCodesStart + lc.code];
+            const uint32_t c2 = sh.off_cl[oc.code];
+            uint64_t bits = c1 & 0xffffu;
+            uint32_t mb = c1 >> 16;
+            bits |= (uint64_t)lc.extra << mb;
+            mb += lc.nextra;
+            bits |= (uint64_t)(c2 & 0xffffu) << mb;
+            mb += c2 >> 16;
+            bits |= (uint64_t)oc.extra << mb;
+            mb += oc.nextra;
+            acc_append(lo, hi, nb, bits, mb);
+          }
         }
-        sink_emit(S, bits, nb, lane);
+        sink_emit_wide(S, lo, hi, nb, lane);
       }
     }
     const uint32_t eob = sh.lit_cl[kEndBlockMarker];
