@@ -30,6 +30,23 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
 
 
+def lz_traffic(args, n, blen):
+    """HBM bytes per launch of the match finder from the separate rocprofv3 --pmc passes
+    (profiles/r01/*pmc_noguests*.json; FETCH_SIZE x2 + WRITE_SIZE, KB -> B).  rocprofv3 serialises
+    kernels while counting, so the concurrent resident+guest launch of the default run cannot be
+    attributed: the figure is only reported for the --no-guests configuration it was measured on."""
+    if not (args.no_guests and args.kind == "text" and n == 16384 and blen == 65536):
+        return None
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01", "v9_pmc_noguests.json")))
+        for k, v in d.items():
+            if "lz77_wave_kernel" in k:
+                return int(v["hbm_bytes_per_launch"])
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -42,6 +59,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-streams", type=int, default=4096)
     ap.add_argument("--verify", type=int, default=64, help="streams checked against the oracle")
+    ap.add_argument("--no-guests", action="store_true",
+                    help="match finder with LDS-table blocks only (no L2-table guest blocks); the "
+                         "configuration the PMC traffic figure in profiles/ was collected on")
     ap.add_argument("--mode", default="deflate", choices=["deflate", "inflate"],
                     help="inflate = BASELINE.json configs[4]: decode the compressed streams (stream index supplied)")
     args = ap.parse_args()
@@ -74,6 +94,8 @@ def main():
     eng = flate.FlateEngine(local_rank)
     eng.use_stream(torch.cuda.current_stream().cuda_stream)
     eng.set_profiling(True)
+    if args.no_guests:
+        eng.set_option("guest_blocks", 0)
     out = torch.empty(in_bytes + (in_bytes >> 3) + 4096, dtype=torch.uint8, device=dev)
 
     if args.mode == "inflate":
@@ -168,7 +190,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": "lz77_wave_kernel", "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None,
+                "traffic": lz_traffic(args, n, blen),
             },
             "cpu_baseline": cpu_baseline,
         }

@@ -550,12 +550,7 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
         // match records of this batch, in position order, one coalesced store
         if ((MF >> lane) & 1) acc_len += (uint32_t)tot_self;
         if ((M >> lane) & 1)
-        {
-          // write-once records: non-temporal, so they do not evict the guests' tables from L2
-          unsigned long long *dst = reinterpret_cast<unsigned long long *>(
-              mout + nm + (uint32_t)__popcll(M & lanes_below(lane)));
-          __builtin_nontemporal_store(((unsigned long long)rec_tok << 32) | (uint32_t)q, dst);
-        }
+          mout[nm + (uint32_t)__popcll(M & lanes_below(lane))] = make_uint2((uint32_t)q, rec_tok);
         nm += (uint32_t)__popcll(M);
         // commit: slots of non-DUP lanes already hold their position (speculative write);
         // un-inserted lanes and every DUP lane restore the old value, then the inserted DUP
