@@ -59,7 +59,9 @@ int flate_hip_set_stream(flate_hip_ctx *ctx, void *hip_stream);
  *   "guest_blocks"       extra persistent wavefronts whose hash table lives in L2 instead of LDS
  *                        (default 4 per CU; 0 = off)
  *   "resident_blocks"    persistent LDS-table wavefronts (default 5 per CU)
- *   "guest_min_streams"  batches smaller than this use one block per stream (default 4096) */
+ *   "guest_min_streams"  batches smaller than this use one block per stream (default 4096)
+ *   "inflate_simt_min_streams"  inflate batches at least this large decode one stream per LANE
+ *                        (64 per wavefront) instead of one per wavefront (default 2048) */
 int flate_hip_set_option(flate_hip_ctx *ctx, const char *name, int64_t value);
 const char *flate_hip_strerror(int code);
 /* Text of the last HIP runtime error seen by this ctx ("" if none). */

@@ -48,6 +48,7 @@ struct flate_hip_ctx {
   int guest_blocks = 0;      // 0 = guest kernel off
   float guest_share = 0.f;   // fraction of the single-window streams given to the guests
   uint32_t guest_min = 4096; // below this many streams the guests stay idle
+  uint32_t inflate_simt_min = 2048;  // batches at least this large use the lane-per-stream inflater
   uint32_t resident_blocks = 1280;  // persistent LDS-table blocks (5 per CU x 256 CUs)
   uint32_t queue_init = 0;
   uint32_t debug_chunks = 0;
@@ -376,6 +377,8 @@ int flate_hip_set_option(flate_hip_ctx *c, const char *name, int64_t value) {
     c->guest_blocks = (int)value;
   } else if (k == "guest_min_streams" && value >= 0) {
     c->guest_min = (uint32_t)value;
+  } else if (k == "inflate_simt_min_streams" && value >= 0) {
+    c->inflate_simt_min = (uint32_t)value;
   } else if (k == "resident_blocks" && value > 0 && value <= 65536) {
     c->resident_blocks = (uint32_t)value;
   } else {
@@ -573,7 +576,12 @@ int flate_hip_inflate_batch(flate_hip_ctx *c, const uint8_t *in, const uint64_t 
   I.n_streams = n;
   {
     StageTimer t(c, FLATE_HIP_STAGE_INFLATE);
-    hipLaunchKernelGGL(inflate_kernel, dim3(n), dim3(64), 0, c->stream, I);
+    // large batches: one lane per stream (64 streams per wavefront); small ones: one wavefront
+    // per stream
+    if (n >= c->inflate_simt_min)
+      hipLaunchKernelGGL(inflate_simt_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, I);
+    else
+      hipLaunchKernelGGL(inflate_kernel, dim3(n), dim3(64), 0, c->stream, I);
   }
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(out_len, c->d_out_len.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));

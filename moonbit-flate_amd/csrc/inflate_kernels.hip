@@ -536,3 +536,518 @@ __global__ __launch_bounds__(64) void inflate_kernel(InfParams P) {
 }
 
 }  // namespace flate
+
+// =======================================================================================
+// SIMT inflater: one LANE per stream (64 streams per wavefront).
+//
+// The wave-per-stream kernel above keeps 63 lanes idle during symbol decoding and is limited
+// to four wavefronts per CU by its 32 KiB LDS window.  For large batches it is better to give
+// every lane its own stream: each lane runs the same decoder state machine (inflate.mbt's step
+// functions) on its own bit stream, the decode tables of the 64 streams are interleaved in LDS
+// (entry i of lane L at u16 index i*64+L) and the history window is the output buffer itself
+// (a lane reads back only bytes it has written).  Divergence is bounded by design: one step of
+// the loop lets every lane either decode one symbol or copy up to eight bytes.
+// =======================================================================================
+namespace flate {
+
+namespace {
+
+constexpr int kSPrimBits = 9, kSPrim = 1 << kSPrimBits;  // literal/length primary table
+constexpr int kSDistBits = 7, kSDist = 1 << kSDistBits;  // distance / code-length primary table
+// per-lane LDS layout, in u16 entries
+constexpr int kOffLitPrim = 0;
+constexpr int kOffDistPrim = kOffLitPrim + kSPrim;       // also the code-length decoder
+constexpr int kOffLitSorted = kOffDistPrim + kSDist;     // 288
+constexpr int kOffDistSorted = kOffLitSorted + 288;      // 32
+constexpr int kOffLitMeta = kOffDistSorted + 32;         // count[16] first[16] offs[16]
+constexpr int kOffDistMeta = kOffLitMeta + 48;
+constexpr int kOffLens = kOffDistMeta + 48;              // code lengths, two per u16
+constexpr int kLaneWords = kOffLens + 176;               // 352 lengths (32 + 286 + 30 used); 1232 u16 per lane
+
+enum SState { S_BLOCK = 0, S_DYN_LENS, S_SYM, S_COPY, S_STORED, S_DONE };
+
+struct LaneLds {
+  uint16_t *base;  // &lds[lane]
+  FLATE_D uint32_t get(int i) const { return base[i * 64]; }
+  FLATE_D void set(int i, uint32_t v) const { base[i * 64] = (uint16_t)v; }
+  FLATE_D uint32_t len_get(int i) const { return (base[(kOffLens + (i >> 1)) * 64] >> ((i & 1) * 8)) & 0xffu; }
+  FLATE_D void len_set(int i, uint32_t v) const {
+    uint16_t &w = base[(kOffLens + (i >> 1)) * 64];
+    w = (uint16_t)((i & 1) ? ((w & 0x00ffu) | (v << 8)) : ((w & 0xff00u) | v));
+  }
+};
+
+// Bit reader of one lane.  `nxt` always holds the dword after the ones already in `buf`, loaded
+// one refill ahead, so a refill never waits for the load it issues.
+struct SBits {
+  const uint8_t *in;
+  uint32_t in_len, roff, ipos, nxt;
+  uint64_t buf;
+  int32_t cnt, avail;
+};
+
+FLATE_D uint32_t sbits_load(const SBits &b, uint32_t pos) {
+  uint32_t w = 0;
+  if (pos + 4 <= b.in_len) {
+    w = ld32g(b.in + pos);
+  } else {
+    for (uint32_t k = pos; k < b.in_len; ++k) w |= (uint32_t)b.in[k] << (8 * (k - pos));
+  }
+  return w;
+}
+FLATE_D void sbits_refill(SBits &b) {
+  if (b.cnt <= 32) {
+    b.buf |= (uint64_t)b.nxt << b.cnt;
+    b.cnt += 32;
+    b.nxt = sbits_load(b, b.ipos);
+    b.ipos += 4;
+  }
+}
+// (re)start reading at byte offset `pos`
+FLATE_D void sbits_start(SBits &b, uint32_t pos) {
+  b.buf = 0;
+  b.cnt = 0;
+  b.avail = 0;
+  b.nxt = sbits_load(b, pos);
+  b.ipos = pos + 4;
+  sbits_refill(b);
+  sbits_refill(b);
+}
+FLATE_D bool sbits_need(SBits &b, int n) {
+  if (n > b.avail) {
+    const int bytes = (n - b.avail + 7) >> 3;
+    if (b.roff + (uint32_t)bytes > b.in_len) {
+      b.roff = b.in_len;
+      return false;
+    }
+    b.roff += (uint32_t)bytes;
+    b.avail += 8 * bytes;
+  }
+  return true;
+}
+FLATE_D void sbits_drop(SBits &b, int n) {
+  b.buf >>= n;
+  b.cnt -= n;
+  b.avail -= n;
+  sbits_refill(b);
+}
+
+// HuffmanDecoder::initialize for one lane: lens[lens_at .. +n) -> primary table + canonical arrays.
+// Returns false for an over/under-subscribed code (inflate.mbt:161); *mn/*mx = min/max length.
+FLATE_D bool sdec_init(const LaneLds &L, int lens_at, int n, int prim_off, int prim_bits, int sorted_off,
+                       int meta_off, int *mn_out, int *mx_out) {
+  const int psize = 1 << prim_bits;
+  for (int i = 0; i < psize; ++i) L.set(prim_off + i, 0);
+  for (int l = 0; l < 16; ++l) L.set(meta_off + l, 0);
+  for (int i = 0; i < n; ++i) {
+    const uint32_t l = L.len_get(lens_at + i);
+    if (l) L.set(meta_off + l, L.get(meta_off + l) + 1);
+  }
+  int mn = 0, mx = 0;
+  for (int l = 1; l < 16; ++l)
+    if (L.get(meta_off + l)) {
+      if (!mn) mn = l;
+      mx = l;
+    }
+  *mn_out = mn;
+  *mx_out = mx;
+  if (mx == 0) return true;  // empty tree (:143-145)
+  uint32_t code = 0, off = 0;
+  for (int l = 1; l < 16; ++l) {
+    code <<= 1;
+    const uint32_t c = L.get(meta_off + l);
+    L.set(meta_off + 16 + l, l >= mn && l <= mx ? code : 0);  // first[l]
+    L.set(meta_off + 32 + l, off);                           // offs[l]
+    if (l >= mn && l <= mx) code += c; else code = (l < mn) ? 0 : code;
+    off += c;
+  }
+  // completeness (:161): recompute as the reference does, from min to max
+  {
+    uint32_t cc = 0;
+    for (int l = mn; l <= mx; ++l) cc = (cc << 1) + L.get(meta_off + l);
+    if (cc != (1u << mx) && !(cc == 1 && mx == 1)) return false;
+  }
+  // canonical assignment in symbol order; the running code/offset per length live in registers
+  uint32_t next_code[16], next_off[16];
+#pragma unroll
+  for (int l = 0; l < 16; ++l) {
+    next_code[l] = 0;
+    next_off[l] = 0;
+  }
+  {
+    uint32_t c2 = 0, o2 = 0;
+#pragma unroll
+    for (int l = 1; l < 16; ++l) {
+      c2 <<= 1;
+      const uint32_t c = L.get(meta_off + l);
+      if (l >= mn && l <= mx) {
+        next_code[l] = c2;
+        c2 += c;
+      }
+      next_off[l] = o2;
+      o2 += c;
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    const uint32_t l = L.len_get(lens_at + i);
+    if (!l) continue;
+    uint32_t code_i = 0, off_i = 0;
+#pragma unroll
+    for (int k = 1; k < 16; ++k)
+      if (l == (uint32_t)k) {
+        code_i = next_code[k]++;
+        off_i = next_off[k]++;
+      }
+    L.set(sorted_off + off_i, (uint32_t)i);
+    if ((int)l <= prim_bits) {
+      const uint32_t rev = __brev(code_i) >> (32 - l);
+      const uint32_t e = ((uint32_t)i << 4) | l;
+      for (uint32_t k = rev; k < (uint32_t)psize; k += 1u << l) L.set(prim_off + k, e);
+    } else {
+      const uint32_t top = code_i >> (l - prim_bits);
+      L.set(prim_off + (__brev(top) >> (32 - prim_bits)), kLongCode);
+    }
+  }
+  return true;
+}
+
+// huff_sym for one lane (inflate.mbt:803-854)
+FLATE_D int shuff_sym(SBits &b, const LaneLds &L, int prim_off, int prim_bits, int sorted_off, int meta_off,
+                      int dmin, int dmax, int *err) {
+  if (!sbits_need(b, dmin)) {
+    *err = E_EOF;
+    return -1;
+  }
+  const uint32_t pmask = (1u << prim_bits) - 1u;
+  const uint32_t e = L.get(prim_off + (int)((uint32_t)b.buf & pmask));
+  if (e == 0) {
+    *err = E_CORRUPT;
+    return -1;
+  }
+  if (e != kLongCode) {
+    const int len = (int)(e & 15u);
+    if (!sbits_need(b, len)) {
+      *err = E_EOF;
+      return -1;
+    }
+    sbits_drop(b, len);
+    return (int)(e >> 4);
+  }
+  uint32_t code = __brev((uint32_t)b.buf & pmask) >> (32 - prim_bits);
+  for (int l = prim_bits + 1; l <= dmax; ++l) {
+    code = (code << 1) | ((uint32_t)(b.buf >> (l - 1)) & 1u);
+    const uint32_t idx = code - L.get(meta_off + 16 + l);
+    if (idx < L.get(meta_off + l)) {
+      if (!sbits_need(b, l)) {
+        *err = E_EOF;
+        return -1;
+      }
+      sbits_drop(b, l);
+      return (int)L.get(sorted_off + (int)(L.get(meta_off + 32 + l) + idx));
+    }
+  }
+  *err = E_CORRUPT;
+  return -1;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
+  __shared__ uint16_t lds[kLaneWords * 64];
+  const int lane = threadIdx.x;
+  const uint32_t sid = blockIdx.x * 64u + (uint32_t)lane;
+  const bool have = sid < P.n_streams;
+  const LaneLds L = {lds + lane};
+
+  SBits b;
+  uint8_t *out = P.out;
+  uint32_t out_cap = 0;
+  b.in = P.in;
+  b.in_len = 0;
+  if (have) {
+    out = P.out + P.out_off[sid];
+    const uint64_t cap64 = P.out_off[sid + 1] - P.out_off[sid];
+    out_cap = cap64 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)cap64;
+    b.in = P.in + P.in_off[sid];
+    b.in_len = (uint32_t)(P.in_off[sid + 1] - P.in_off[sid]);
+  }
+  b.roff = 0;
+  b.ipos = 0;
+  b.nxt = 0;
+  b.buf = 0;
+  b.cnt = 0;
+  b.avail = 0;
+  if (have) sbits_start(b, 0);
+  uint32_t opos = 0;
+  int state = have ? S_BLOCK : S_DONE;
+  int err = 0;
+  bool final_block = false;
+  int lit_min = 0, lit_max = 0, dist_min = 0, dist_max = 0, cl_min = 0, cl_max = 0;
+  int hdr_i = 0, hdr_n = 0, hdr_nlit = 0, hdr_ndist = 0;
+  uint32_t copy_len = 0, copy_dist = 0;  // S_COPY: LZ77 copy; S_STORED: copy_len raw bytes left
+  uint32_t pend_lo = 0, pend_hi = 0;     // S_COPY: the next (up to) 8 source bytes, loaded a step ahead
+  // loads the source bytes of the next copy step: min(copy_len, copy_dist, 8) of them are valid
+  auto copy_fetch = [&]() {
+    const uint8_t *src = out + opos - copy_dist;
+    if (opos - copy_dist + 8u <= out_cap) {  // the 8-byte read stays inside this stream's slot
+      pend_lo = ld32g(src);
+      pend_hi = ld32g(src + 4);
+    } else {
+      uint32_t k = copy_len < copy_dist ? copy_len : copy_dist;
+      if (k > 8u) k = 8u;
+      uint64_t v = 0;
+      for (uint32_t i = 0; i < k; ++i) v |= (uint64_t)src[i] << (8 * i);
+      pend_lo = (uint32_t)v;
+      pend_hi = (uint32_t)(v >> 32);
+    }
+  };
+
+  for (uint32_t guard = 0; guard < 0x20000000u; ++guard) {
+    if (__ballot(state != S_DONE) == 0) break;
+
+    if (state == S_BLOCK) {  // next_block (inflate.mbt:345-379)
+      if (final_block) {
+        state = S_DONE;
+      } else if (!sbits_need(b, 3)) {
+        err = E_EOF;
+      } else {
+        const uint32_t h = (uint32_t)b.buf & 7u;
+        final_block = h & 1;
+        const uint32_t typ = h >> 1;
+        sbits_drop(b, 3);
+        if (typ == 3) {
+          err = E_CORRUPT;
+        } else if (typ == 0) {  // data_block (:708-737)
+          const uint32_t p = b.roff;
+          if (b.in_len - p < 4) {
+            b.roff = b.in_len;
+            err = E_EOF;
+          } else {
+            b.roff = p + 4;
+            const uint32_t n = (uint32_t)b.in[p] | ((uint32_t)b.in[p + 1] << 8);
+            const uint32_t nn = (uint32_t)b.in[p + 2] | ((uint32_t)b.in[p + 3] << 8);
+            if ((nn & 0xffffu) != ((~n) & 0xffffu)) {
+              err = E_CORRUPT;
+            } else {
+              copy_len = n;
+              state = S_STORED;
+            }
+          }
+        } else if (typ == 1) {  // fixed tables (:886-939); distances are 5-bit codes
+          for (int i = 0; i < 288; ++i) L.len_set(i, i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8)));
+          for (int i = 0; i < 32; ++i) L.len_set(288 + i, 5);
+          sdec_init(L, 0, 288, kOffLitPrim, kSPrimBits, kOffLitSorted, kOffLitMeta, &lit_min, &lit_max);
+          sdec_init(L, 288, 32, kOffDistPrim, kSDistBits, kOffDistSorted, kOffDistMeta, &dist_min, &dist_max);
+          state = S_SYM;
+        } else {  // read_huffman (:429-470)
+          if (!sbits_need(b, 14)) {
+            err = E_EOF;
+          } else {
+            const uint32_t v = (uint32_t)b.buf & 0x3fffu;
+            hdr_nlit = (int)(v & 31u) + 257;
+            hdr_ndist = (int)((v >> 5) & 31u) + 1;
+            const int nclen = (int)((v >> 10) & 15u) + 4;
+            if (hdr_nlit > kMaxLit || hdr_ndist > kMaxDist) {
+              err = E_CORRUPT;
+            } else {
+              sbits_drop(b, 14);
+              for (int i = 0; i < kNumCodes; ++i) L.len_set(i, 0);
+              for (int i = 0; i < nclen && !err; ++i) {
+                if (!sbits_need(b, 3)) {
+                  err = E_EOF;
+                } else {
+                  L.len_set(kCodeOrder[i], (uint32_t)b.buf & 7u);
+                  sbits_drop(b, 3);
+                }
+              }
+              if (!err) {
+                if (!sdec_init(L, 0, kNumCodes, kOffDistPrim, kSDistBits, kOffDistSorted, kOffDistMeta,
+                               &cl_min, &cl_max)) {
+                  err = E_CORRUPT;
+                } else {
+                  hdr_i = 0;
+                  hdr_n = hdr_nlit + hdr_ndist;
+                  state = S_DYN_LENS;
+                }
+              }
+            }
+          }
+        }
+      }
+    } else if (state == S_DYN_LENS) {  // :471-536, one code-length symbol per step
+      if (hdr_i >= hdr_n) {
+        // the code-length decoder sits in the distance slots: build literal first (it only
+        // reads lens), then distance
+        bool ok = sdec_init(L, 32, hdr_nlit, kOffLitPrim, kSPrimBits, kOffLitSorted, kOffLitMeta,
+                            &lit_min, &lit_max);
+        ok = sdec_init(L, 32 + hdr_nlit, hdr_ndist, kOffDistPrim, kSDistBits, kOffDistSorted,
+                       kOffDistMeta, &dist_min, &dist_max) && ok;
+        if (!ok) {
+          err = E_CORRUPT;
+        } else {
+          const int eob = (int)L.len_get(32 + 256);
+          if (lit_min < eob) lit_min = eob;  // :542-544
+          state = S_SYM;
+        }
+      } else {
+        const int x = shuff_sym(b, L, kOffDistPrim, kSDistBits, kOffDistSorted, kOffDistMeta, cl_min,
+                                cl_max, &err);
+        if (x >= 0) {
+          if (x < 16) {
+            L.len_set(32 + hdr_i, (uint32_t)x);
+            ++hdr_i;
+          } else {
+            int rep, nb;
+            uint32_t fill = 0;
+            bool bad = false;
+            if (x == 16) {
+              rep = 3;
+              nb = 2;
+              if (hdr_i == 0) bad = true; else fill = L.len_get(32 + hdr_i - 1);
+            } else if (x == 17) {
+              rep = 3;
+              nb = 3;
+            } else {
+              rep = 11;
+              nb = 7;
+            }
+            if (bad) {
+              err = E_CORRUPT;
+            } else if (!sbits_need(b, nb)) {
+              err = E_EOF;
+            } else {
+              rep += (int)((uint32_t)b.buf & ((1u << nb) - 1u));
+              sbits_drop(b, nb);
+              if (hdr_i + rep > hdr_n) {
+                err = E_CORRUPT;
+              } else {
+                for (int j = 0; j < rep; ++j) L.len_set(32 + hdr_i + j, fill);
+                hdr_i += rep;
+              }
+            }
+          }
+        }
+      }
+    } else if (state == S_SYM) {  // read_literal (:565-684)
+      const int v = shuff_sym(b, L, kOffLitPrim, kSPrimBits, kOffLitSorted, kOffLitMeta, lit_min, lit_max,
+                              &err);
+      if (v >= 0) {
+        if (v < 256) {
+          if (opos >= out_cap) {
+            err = E_OUT_SMALL;
+          } else {
+            out[opos++] = (uint8_t)v;
+          }
+        } else if (v == 256) {
+          state = S_BLOCK;  // finish_block
+        } else {
+          int length = 0, n = 0;
+          if (v < 265) {
+            length = v - (257 - 3);
+          } else if (v < 269) {
+            length = v * 2 - (265 * 2 - 11);
+            n = 1;
+          } else if (v < 273) {
+            length = v * 4 - (269 * 4 - 19);
+            n = 2;
+          } else if (v < 277) {
+            length = v * 8 - (273 * 8 - 35);
+            n = 3;
+          } else if (v < 281) {
+            length = v * 16 - (277 * 16 - 67);
+            n = 4;
+          } else if (v < 285) {
+            length = v * 32 - (281 * 32 - 131);
+            n = 5;
+          } else if (v < kMaxLit) {
+            length = 258;
+          } else {
+            err = E_CORRUPT;
+          }
+          if (!err && n > 0) {
+            if (!sbits_need(b, n)) {
+              err = E_EOF;
+            } else {
+              length += (int)((uint32_t)b.buf & ((1u << n) - 1u));
+              sbits_drop(b, n);
+            }
+          }
+          if (!err) {
+            int dist = shuff_sym(b, L, kOffDistPrim, kSDistBits, kOffDistSorted, kOffDistMeta, dist_min,
+                                 dist_max, &err);
+            if (dist >= 0) {
+              if (dist < 4) {
+                dist += 1;
+              } else if (dist < kMaxDist) {
+                const int nb = (dist - 2) >> 1;
+                int extra = (dist & 1) << nb;
+                if (!sbits_need(b, nb)) {
+                  err = E_EOF;
+                } else {
+                  extra |= (int)((uint32_t)b.buf & ((1u << nb) - 1u));
+                  sbits_drop(b, nb);
+                  dist = (1 << (nb + 1)) + 1 + extra;
+                }
+              } else {
+                err = E_CORRUPT;
+              }
+              if (!err) {
+                const uint32_t hist = opos < 32768u ? opos : 32768u;  // hist_size
+                if ((uint32_t)dist > hist) {
+                  err = E_CORRUPT;
+                } else if ((uint32_t)length > out_cap - opos) {
+                  err = E_OUT_SMALL;
+                } else {
+                  copy_len = (uint32_t)length;
+                  copy_dist = (uint32_t)dist;
+                  copy_fetch();
+                  state = S_COPY;
+                }
+              }
+            }
+          }
+        }
+      }
+    } else if (state == S_COPY) {  // copy_history (:689) / write_copy: up to 8 bytes per step
+      uint32_t k = copy_len < copy_dist ? copy_len : copy_dist;  // source bytes that already exist
+      if (k > 8u) k = 8u;
+      if (k == 8u) {
+        __builtin_memcpy(out + opos, &pend_lo, 4);
+        __builtin_memcpy(out + opos + 4, &pend_hi, 4);
+      } else {
+        const uint64_t v = ((uint64_t)pend_hi << 32) | pend_lo;
+        for (uint32_t i = 0; i < k; ++i) out[opos + i] = (uint8_t)(v >> (8 * i));
+      }
+      opos += k;
+      copy_len -= k;
+      if (copy_len == 0) state = S_SYM; else copy_fetch();
+    } else if (state == S_STORED) {  // copy_data (:742-766): 8 raw bytes per step
+      if (copy_len == 0) {
+        sbits_start(b, b.roff);  // restart the bit reader at the byte after the block
+        state = S_BLOCK;
+      } else {
+        const uint32_t avail = b.in_len - b.roff;
+        uint32_t k = copy_len < 8u ? copy_len : 8u;
+        if (k > avail) k = avail;
+        if (k > out_cap - opos) {
+          err = E_OUT_SMALL;
+        } else if (k == 0) {
+          err = E_EOF;
+        } else {
+          for (uint32_t i = 0; i < k; ++i) out[opos + i] = b.in[b.roff + i];
+          opos += k;
+          b.roff += k;
+          copy_len -= k;
+        }
+      }
+    }
+    if (err && state != S_DONE) state = S_DONE;
+  }
+  if (have) {
+    P.out_len[sid] = opos;
+    P.status[sid] = err;
+    P.err_off[sid] = err == E_CORRUPT ? (long long)b.roff : -1;
+  }
+}
+
+}  // namespace flate

@@ -9,10 +9,12 @@ from util import flate, make_streams
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def eng():
+@pytest.fixture(scope="module", params=["wave_per_stream", "lane_per_stream"])
+def eng(request):
+    """Both inflater kernels must pass every test: the option forces one or the other."""
     flate.build()
     e = flate.FlateEngine(0)
+    e.set_option("inflate_simt_min_streams", 0 if request.param == "lane_per_stream" else 1 << 30)
     yield e
     e.close()
 
