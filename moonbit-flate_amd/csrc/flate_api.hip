@@ -578,7 +578,10 @@ int flate_hip_inflate_batch(flate_hip_ctx *c, const uint8_t *in, const uint64_t 
     StageTimer t(c, FLATE_HIP_STAGE_INFLATE);
     // large batches: one lane per stream (64 streams per wavefront); small ones: one wavefront
     // per stream
-    if (n >= c->inflate_simt_min)
+    // (its bit positions are 32-bit: every compressed stream must be < 256 MiB)
+    bool simt = n >= c->inflate_simt_min;
+    for (uint32_t i = 0; i < n && simt; ++i) simt = in_off[i + 1] - in_off[i] < (1ull << 28);
+    if (simt)
       hipLaunchKernelGGL(inflate_simt_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, I);
     else
       hipLaunchKernelGGL(inflate_kernel, dim3(n), dim3(64), 0, c->stream, I);

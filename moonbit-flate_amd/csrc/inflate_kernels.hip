@@ -564,7 +564,7 @@ constexpr int kOffDistMeta = kOffLitMeta + 48;
 constexpr int kOffLens = kOffDistMeta + 48;              // code lengths, two per u16
 constexpr int kLaneWords = kOffLens + 176;               // 352 lengths (32 + 286 + 30 used); 1232 u16 per lane
 
-enum SState { S_BLOCK = 0, S_DYN_LENS, S_SYM, S_COPY, S_STORED, S_DONE };
+enum SState { S_BLOCK = 0, S_DYN_LENS, S_SYM, S_DIST, S_STORED, S_DONE };
 
 struct LaneLds {
   uint16_t *base;  // &lds[lane]
@@ -577,16 +577,19 @@ struct LaneLds {
   }
 };
 
-// Bit reader of one lane.  `nxt` always holds the dword after the ones already in `buf`, loaded
-// one refill ahead, so a refill never waits for the load it issues.
+// Bit reader of one lane: the consumed-bit position plus the two dwords under it; `nxt` is the
+// dword after those, always requested one step ahead.  The reference reads its input byte-wise
+// (inflate.mbt:771 more_bits); its roffset -- reported by corrupt_input_error -- equals
+// ceil(hi / 8), hi = the highest bit position any read has asked for.
 struct SBits {
   const uint8_t *in;
-  uint32_t in_len, roff, ipos, nxt;
-  uint64_t buf;
-  int32_t cnt, avail;
+  uint32_t in_len, in_bits;
+  uint32_t bitpos, hi;
+  uint32_t w0, w1, nxt, widx;  // w0 = dword widx of the stream, w1 = widx+1, nxt = widx+2
 };
 
-FLATE_D uint32_t sbits_load(const SBits &b, uint32_t pos) {
+FLATE_D uint32_t sb_load(const SBits &b, uint32_t widx) {
+  const uint32_t pos = widx * 4u;
   uint32_t w = 0;
   if (pos + 4 <= b.in_len) {
     w = ld32g(b.in + pos);
@@ -595,47 +598,44 @@ FLATE_D uint32_t sbits_load(const SBits &b, uint32_t pos) {
   }
   return w;
 }
-FLATE_D void sbits_refill(SBits &b) {
-  if (b.cnt <= 32) {
-    b.buf |= (uint64_t)b.nxt << b.cnt;
-    b.cnt += 32;
-    b.nxt = sbits_load(b, b.ipos);
-    b.ipos += 4;
+FLATE_D void sb_start(SBits &b, uint32_t byte_pos) {
+  b.bitpos = b.hi = byte_pos * 8u;
+  b.widx = byte_pos >> 2;
+  b.w0 = sb_load(b, b.widx);
+  b.w1 = sb_load(b, b.widx + 1);
+  b.nxt = sb_load(b, b.widx + 2);
+}
+// the next 32 bits; valid while bitpos is inside w0/w1, i.e. after <= 32 bits taken since a sync
+FLATE_D uint32_t sb_peek(const SBits &b) {
+  return (uint32_t)((((uint64_t)b.w1 << 32) | b.w0) >> (b.bitpos - b.widx * 32u));
+}
+FLATE_D bool sb_need(SBits &b, uint32_t n) {
+  const uint32_t t = b.bitpos + n;
+  b.hi = b.hi > t ? b.hi : t;
+  return t <= b.in_bits;
+}
+FLATE_D void sb_take(SBits &b, uint32_t n) { b.bitpos += n; }
+// blocking catch-up for the block-header states (the hot states advance in the step loop)
+FLATE_D void sb_sync(SBits &b) {
+  while ((b.bitpos >> 5) != b.widx) {
+    b.w0 = b.w1;
+    b.w1 = b.nxt;
+    ++b.widx;
+    b.nxt = sb_load(b, b.widx + 2);
   }
 }
-// (re)start reading at byte offset `pos`
-FLATE_D void sbits_start(SBits &b, uint32_t pos) {
-  b.buf = 0;
-  b.cnt = 0;
-  b.avail = 0;
-  b.nxt = sbits_load(b, pos);
-  b.ipos = pos + 4;
-  sbits_refill(b);
-  sbits_refill(b);
-}
-FLATE_D bool sbits_need(SBits &b, int n) {
-  if (n > b.avail) {
-    const int bytes = (n - b.avail + 7) >> 3;
-    if (b.roff + (uint32_t)bytes > b.in_len) {
-      b.roff = b.in_len;
-      return false;
-    }
-    b.roff += (uint32_t)bytes;
-    b.avail += 8 * bytes;
-  }
-  return true;
-}
-FLATE_D void sbits_drop(SBits &b, int n) {
-  b.buf >>= n;
-  b.cnt -= n;
-  b.avail -= n;
-  sbits_refill(b);
-}
+FLATE_D uint32_t sb_roffset(const SBits &b) { return (b.hi + 7u) >> 3; }
 
 // HuffmanDecoder::initialize for one lane: lens[lens_at .. +n) -> primary table + canonical arrays.
 // Returns false for an over/under-subscribed code (inflate.mbt:161); *mn/*mx = min/max length.
+// lim[k - prim_bits - 1] (k = prim_bits+1 .. 15) = exclusive upper bound of the codes of length <= k,
+// left-justified to 15 bits: the loop-free length search of shuff_sym.  meta+16+l holds
+// offs[l] - first[l] (mod 2^16), so sorted index = code + that.
+template <int NLIM>
 FLATE_D bool sdec_init(const LaneLds &L, int lens_at, int n, int prim_off, int prim_bits, int sorted_off,
-                       int meta_off, int *mn_out, int *mx_out) {
+                       int meta_off, int *mn_out, int *mx_out, uint32_t (&lim)[NLIM]) {
+#pragma unroll
+  for (int k = 0; k < NLIM; ++k) lim[k] = 0;
   const int psize = 1 << prim_bits;
   for (int i = 0; i < psize; ++i) L.set(prim_off + i, 0);
   for (int l = 0; l < 16; ++l) L.set(meta_off + l, 0);
@@ -656,9 +656,8 @@ FLATE_D bool sdec_init(const LaneLds &L, int lens_at, int n, int prim_off, int p
   for (int l = 1; l < 16; ++l) {
     code <<= 1;
     const uint32_t c = L.get(meta_off + l);
-    L.set(meta_off + 16 + l, l >= mn && l <= mx ? code : 0);  // first[l]
-    L.set(meta_off + 32 + l, off);                           // offs[l]
-    if (l >= mn && l <= mx) code += c; else code = (l < mn) ? 0 : code;
+    L.set(meta_off + 16 + l, (off - code) & 0xffffu);  // offs[l] - first[l]
+    code += c;
     off += c;
   }
   // completeness (:161): recompute as the reference does, from min to max
@@ -680,12 +679,11 @@ FLATE_D bool sdec_init(const LaneLds &L, int lens_at, int n, int prim_off, int p
     for (int l = 1; l < 16; ++l) {
       c2 <<= 1;
       const uint32_t c = L.get(meta_off + l);
-      if (l >= mn && l <= mx) {
-        next_code[l] = c2;
-        c2 += c;
-      }
+      next_code[l] = c2;
+      c2 += c;
       next_off[l] = o2;
       o2 += c;
+      if (l > prim_bits && l - prim_bits - 1 < NLIM) lim[l - prim_bits - 1] = c2 << (15 - l);
     }
   }
   for (int i = 0; i < n; ++i) {
@@ -711,43 +709,38 @@ FLATE_D bool sdec_init(const LaneLds &L, int lens_at, int n, int prim_off, int p
   return true;
 }
 
-// huff_sym for one lane (inflate.mbt:803-854)
+// huff_sym for one lane (inflate.mbt:803-854); never loads (see the step loop).  Codes longer than
+// the primary table are resolved without a loop: the code length is the number of limits the
+// next 15 bits (MSB first) reach, the symbol sits at code + (offs - first) in the sorted list.
+// Returns the symbol, or -1 with *err set.
+template <int NLIM>
 FLATE_D int shuff_sym(SBits &b, const LaneLds &L, int prim_off, int prim_bits, int sorted_off, int meta_off,
-                      int dmin, int dmax, int *err) {
-  if (!sbits_need(b, dmin)) {
+                      int dmin, const uint32_t (&lim)[NLIM], int *err) {
+  const uint32_t w = sb_peek(b);
+  const uint32_t e = L.get(prim_off + (int)(w & ((1u << prim_bits) - 1u)));
+  if (!sb_need(b, (uint32_t)dmin)) {
     *err = E_EOF;
     return -1;
   }
-  const uint32_t pmask = (1u << prim_bits) - 1u;
-  const uint32_t e = L.get(prim_off + (int)((uint32_t)b.buf & pmask));
-  if (e == 0) {
+  uint32_t len = e & 15u, sym = e >> 4;
+  if (e == kLongCode) {
+    const uint32_t c15 = __brev(w) >> 17;
+    len = (uint32_t)prim_bits + 1u;
+#pragma unroll
+    for (int k = 0; k < NLIM; ++k) len += c15 >= lim[k] ? 1u : 0u;
+    if (len > 15u) len = 0;  // no code: corrupt
+    else sym = L.get(sorted_off + (int)(((c15 >> (15u - len)) + L.get(meta_off + 16 + (int)len)) & 0xffffu));
+  }
+  if (len == 0) {  // e == 0: unused primary slot
     *err = E_CORRUPT;
     return -1;
   }
-  if (e != kLongCode) {
-    const int len = (int)(e & 15u);
-    if (!sbits_need(b, len)) {
-      *err = E_EOF;
-      return -1;
-    }
-    sbits_drop(b, len);
-    return (int)(e >> 4);
+  if (!sb_need(b, len)) {
+    *err = E_EOF;
+    return -1;
   }
-  uint32_t code = __brev((uint32_t)b.buf & pmask) >> (32 - prim_bits);
-  for (int l = prim_bits + 1; l <= dmax; ++l) {
-    code = (code << 1) | ((uint32_t)(b.buf >> (l - 1)) & 1u);
-    const uint32_t idx = code - L.get(meta_off + 16 + l);
-    if (idx < L.get(meta_off + l)) {
-      if (!sbits_need(b, l)) {
-        *err = E_EOF;
-        return -1;
-      }
-      sbits_drop(b, l);
-      return (int)L.get(sorted_off + (int)(L.get(meta_off + 32 + l) + idx));
-    }
-  }
-  *err = E_CORRUPT;
-  return -1;
+  sb_take(b, len);
+  return (int)sym;
 }
 
 }  // namespace
@@ -769,61 +762,171 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
     const uint64_t cap64 = P.out_off[sid + 1] - P.out_off[sid];
     out_cap = cap64 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)cap64;
     b.in = P.in + P.in_off[sid];
-    b.in_len = (uint32_t)(P.in_off[sid + 1] - P.in_off[sid]);
+    b.in_len = (uint32_t)(P.in_off[sid + 1] - P.in_off[sid]);  // < 2^28: checked by the host
   }
-  b.roff = 0;
-  b.ipos = 0;
-  b.nxt = 0;
-  b.buf = 0;
-  b.cnt = 0;
-  b.avail = 0;
-  if (have) sbits_start(b, 0);
+  b.in_bits = b.in_len * 8u;
+  b.bitpos = b.hi = b.widx = 0;
+  b.w0 = b.w1 = b.nxt = 0;
+  if (have) sb_start(b, 0);
   uint32_t opos = 0;
   int state = have ? S_BLOCK : S_DONE;
   int err = 0;
   bool final_block = false;
   int lit_min = 0, lit_max = 0, dist_min = 0, dist_max = 0, cl_min = 0, cl_max = 0;
   int hdr_i = 0, hdr_n = 0, hdr_nlit = 0, hdr_ndist = 0;
-  uint32_t copy_len = 0, copy_dist = 0;  // S_COPY: LZ77 copy; S_STORED: copy_len raw bytes left
-  uint32_t pend_lo = 0, pend_hi = 0;     // S_COPY: the next (up to) 8 source bytes, loaded a step ahead
-  // loads the source bytes of the next copy step: min(copy_len, copy_dist, 8) of them are valid
-  auto copy_fetch = [&]() {
-    const uint8_t *src = out + opos - copy_dist;
-    if (opos - copy_dist + 8u <= out_cap) {  // the 8-byte read stays inside this stream's slot
-      pend_lo = ld32g(src);
-      pend_hi = ld32g(src + 4);
-    } else {
-      uint32_t k = copy_len < copy_dist ? copy_len : copy_dist;
-      if (k > 8u) k = 8u;
-      uint64_t v = 0;
-      for (uint32_t i = 0; i < k; ++i) v |= (uint64_t)src[i] << (8 * i);
-      pend_lo = (uint32_t)v;
-      pend_hi = (uint32_t)(v >> 32);
-    }
-  };
+  uint32_t lit_lim[15 - kSPrimBits], dist_lim[15 - kSDistBits];  // see shuff_sym
+  uint32_t match_len = 0;                // S_DIST: the length decoded by S_SYM
+  uint32_t copy_len = 0, copy_dist = 0;  // LZ77 copy in flight (S_STORED: raw bytes left in copy_len)
+  uint32_t pend_lo = 0, pend_hi = 0;     // its next (up to) 8 source bytes, requested a step ahead
 
+  // One step: (1) the state blocks -- ALU and LDS only in the hot states (S_SYM, S_DIST,
+  // S_DYN_LENS), they read the bit window but never touch global memory; (2) the stores, which
+  // consume the copy bytes requested at the end of the previous step, and the advance of the bit
+  // window into the dword requested then; (3) the loads for the next step.  The wavefront has one
+  // vmcnt counter for all lanes, so this order gives one memory wait per step, overlapped with
+  // (1).  A hot state takes at most 15+13 bits per step, so the 64-bit window never runs dry.
+  // A lane decodes its next symbol in the same step that stores the last chunk of its copy.
   for (uint32_t guard = 0; guard < 0x20000000u; ++guard) {
-    if (__ballot(state != S_DONE) == 0) break;
+    if (__ballot(state != S_DONE || copy_len != 0) == 0) break;
 
-    if (state == S_BLOCK) {  // next_block (inflate.mbt:345-379)
-      if (final_block) {
-        state = S_DONE;
-      } else if (!sbits_need(b, 3)) {
-        err = E_EOF;
-      } else {
-        const uint32_t h = (uint32_t)b.buf & 7u;
-        final_block = h & 1;
-        const uint32_t typ = h >> 1;
-        sbits_drop(b, 3);
-        if (typ == 3) {
+    uint32_t k = 0;  // bytes of the copy in flight that go out this step
+    if (state != S_STORED && copy_len != 0) {
+      k = copy_len < copy_dist ? copy_len : copy_dist;  // source bytes that already exist
+      if (k > 8u) k = 8u;
+    }
+    const bool last_chunk = copy_len == k;
+    const uint32_t opos_eff = opos + k;
+    bool lit_store = false, new_match = false;
+    uint32_t lit_val = 0, new_dist = 0;
+
+    if (state == S_SYM && last_chunk) {  // read_literal (:565-630): literal/length symbol + extra
+      const int v = shuff_sym(b, L, kOffLitPrim, kSPrimBits, kOffLitSorted, kOffLitMeta, lit_min, lit_lim,
+                              &err);
+      if (v >= 0) {
+        if (v < 256) {
+          lit_store = opos_eff < out_cap;
+          lit_val = (uint32_t)v;
+          if (!lit_store) err = E_OUT_SMALL;
+        } else if (v == 256) {
+          state = S_BLOCK;  // finish_block
+        } else if (v > 285) {
           err = E_CORRUPT;
-        } else if (typ == 0) {  // data_block (:708-737)
-          const uint32_t p = b.roff;
-          if (b.in_len - p < 4) {
-            b.roff = b.in_len;
+        } else {
+          // :590-617 in closed form: 257..264 -> 3..10; 265..284 -> ((4|(x&3)) << n) + 3, x = v-261
+          uint32_t length = (uint32_t)v - 254u, n = 0;
+          if (v >= 265) {
+            n = ((uint32_t)v - 261u) >> 2;
+            length = ((4u | (((uint32_t)v - 261u) & 3u)) << n) + 3u;
+          }
+          if (v == 285) {
+            length = 258;
+            n = 0;
+          }
+          const uint32_t w = sb_peek(b);
+          if (!sb_need(b, n)) {
             err = E_EOF;
           } else {
-            b.roff = p + 4;
+            sb_take(b, n);
+            match_len = length + (w & ((1u << n) - 1u));
+            state = S_DIST;
+          }
+        }
+      }
+    } else if (state == S_DIST && last_chunk) {  // read_literal (:631-684): distance symbol + extra
+      const int d = shuff_sym(b, L, kOffDistPrim, kSDistBits, kOffDistSorted, kOffDistMeta, dist_min,
+                              dist_lim, &err);
+      if (d >= 0) {
+        if (d >= kMaxDist) {
+          err = E_CORRUPT;
+        } else {
+          const uint32_t nb = d < 4 ? 0u : (uint32_t)(d - 2) >> 1;
+          const uint32_t w = sb_peek(b);
+          if (!sb_need(b, nb)) {
+            err = E_EOF;
+          } else {
+            sb_take(b, nb);
+            const uint32_t dist =
+                d < 4 ? (uint32_t)d + 1u : (1u << (nb + 1)) + 1u + (((uint32_t)d & 1u) << nb) + (w & ((1u << nb) - 1u));
+            const uint32_t hist = opos_eff < 32768u ? opos_eff : 32768u;  // hist_size
+            if (dist > hist) {
+              err = E_CORRUPT;
+            } else if (match_len > out_cap - opos_eff) {
+              err = E_OUT_SMALL;
+            } else {
+              new_match = true;
+              new_dist = dist;
+              state = S_SYM;
+            }
+          }
+        }
+      }
+    } else if (state == S_DYN_LENS && copy_len == 0) {  // :471-536, one code-length symbol per step
+      if (hdr_i >= hdr_n) {
+        // the code-length decoder sits in the distance slots: build literal first (it only
+        // reads lens), then distance
+        bool ok = sdec_init(L, 32, hdr_nlit, kOffLitPrim, kSPrimBits, kOffLitSorted, kOffLitMeta,
+                            &lit_min, &lit_max, lit_lim);
+        ok = sdec_init(L, 32 + hdr_nlit, hdr_ndist, kOffDistPrim, kSDistBits, kOffDistSorted,
+                       kOffDistMeta, &dist_min, &dist_max, dist_lim) && ok;
+        if (!ok) {
+          err = E_CORRUPT;
+        } else {
+          const int eob = (int)L.len_get(32 + 256);
+          if (lit_min < eob) lit_min = eob;  // :542-544
+          state = S_SYM;
+        }
+      } else {
+        const int x = shuff_sym(b, L, kOffDistPrim, kSDistBits, kOffDistSorted, kOffDistMeta, cl_min,
+                                dist_lim, &err);
+        if (x >= 0) {
+          if (x < 16) {
+            L.len_set(32 + hdr_i, (uint32_t)x);
+            ++hdr_i;
+          } else {
+            int rep = x == 18 ? 11 : 3;
+            const uint32_t nb = x == 16 ? 2u : (x == 17 ? 3u : 7u);
+            uint32_t fill = 0;
+            if (x == 16 && hdr_i == 0) {
+              err = E_CORRUPT;
+            } else {
+              if (x == 16) fill = L.len_get(32 + hdr_i - 1);
+              const uint32_t w = sb_peek(b);
+              if (!sb_need(b, nb)) {
+                err = E_EOF;
+              } else {
+                sb_take(b, nb);
+                rep += (int)(w & ((1u << nb) - 1u));
+                if (hdr_i + rep > hdr_n) {
+                  err = E_CORRUPT;
+                } else {
+                  for (int j = 0; j < rep; ++j) L.len_set(32 + hdr_i + j, fill);
+                  hdr_i += rep;
+                }
+              }
+            }
+          }
+        }
+      }
+    } else if (state == S_BLOCK && copy_len == 0) {  // next_block (inflate.mbt:345-379)
+      sb_sync(b);
+      if (final_block) {
+        state = S_DONE;
+      } else if (!sb_need(b, 3)) {
+        err = E_EOF;
+      } else {
+        const uint32_t h = sb_peek(b) & 7u;
+        final_block = h & 1;
+        const uint32_t typ = h >> 1;
+        sb_take(b, 3);
+        if (typ == 3) {
+          err = E_CORRUPT;
+        } else if (typ == 0) {  // data_block (:708-737): header bytes follow the bytes read so far
+          const uint32_t p = sb_roffset(b);
+          if (b.in_len - p < 4) {
+            b.hi = b.in_bits;
+            err = E_EOF;
+          } else {
+            b.hi = (p + 4) * 8u;
             const uint32_t n = (uint32_t)b.in[p] | ((uint32_t)b.in[p + 1] << 8);
             const uint32_t nn = (uint32_t)b.in[p + 2] | ((uint32_t)b.in[p + 3] << 8);
             if ((nn & 0xffffu) != ((~n) & 0xffffu)) {
@@ -836,33 +939,37 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
         } else if (typ == 1) {  // fixed tables (:886-939); distances are 5-bit codes
           for (int i = 0; i < 288; ++i) L.len_set(i, i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8)));
           for (int i = 0; i < 32; ++i) L.len_set(288 + i, 5);
-          sdec_init(L, 0, 288, kOffLitPrim, kSPrimBits, kOffLitSorted, kOffLitMeta, &lit_min, &lit_max);
-          sdec_init(L, 288, 32, kOffDistPrim, kSDistBits, kOffDistSorted, kOffDistMeta, &dist_min, &dist_max);
+          sdec_init(L, 0, 288, kOffLitPrim, kSPrimBits, kOffLitSorted, kOffLitMeta, &lit_min, &lit_max,
+                    lit_lim);
+          sdec_init(L, 288, 32, kOffDistPrim, kSDistBits, kOffDistSorted, kOffDistMeta, &dist_min, &dist_max,
+                    dist_lim);
           state = S_SYM;
         } else {  // read_huffman (:429-470)
-          if (!sbits_need(b, 14)) {
+          if (!sb_need(b, 14)) {
             err = E_EOF;
           } else {
-            const uint32_t v = (uint32_t)b.buf & 0x3fffu;
+            const uint32_t v = sb_peek(b) & 0x3fffu;
             hdr_nlit = (int)(v & 31u) + 257;
             hdr_ndist = (int)((v >> 5) & 31u) + 1;
             const int nclen = (int)((v >> 10) & 15u) + 4;
             if (hdr_nlit > kMaxLit || hdr_ndist > kMaxDist) {
               err = E_CORRUPT;
             } else {
-              sbits_drop(b, 14);
+              sb_take(b, 14);
+              sb_sync(b);
               for (int i = 0; i < kNumCodes; ++i) L.len_set(i, 0);
               for (int i = 0; i < nclen && !err; ++i) {
-                if (!sbits_need(b, 3)) {
+                if (!sb_need(b, 3)) {
                   err = E_EOF;
                 } else {
-                  L.len_set(kCodeOrder[i], (uint32_t)b.buf & 7u);
-                  sbits_drop(b, 3);
+                  L.len_set(kCodeOrder[i], sb_peek(b) & 7u);
+                  sb_take(b, 3);
+                  sb_sync(b);
                 }
               }
               if (!err) {
                 if (!sdec_init(L, 0, kNumCodes, kOffDistPrim, kSDistBits, kOffDistSorted, kOffDistMeta,
-                               &cl_min, &cl_max)) {
+                               &cl_min, &cl_max, dist_lim)) {
                   err = E_CORRUPT;
                 } else {
                   hdr_i = 0;
@@ -874,179 +981,89 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
           }
         }
       }
-    } else if (state == S_DYN_LENS) {  // :471-536, one code-length symbol per step
-      if (hdr_i >= hdr_n) {
-        // the code-length decoder sits in the distance slots: build literal first (it only
-        // reads lens), then distance
-        bool ok = sdec_init(L, 32, hdr_nlit, kOffLitPrim, kSPrimBits, kOffLitSorted, kOffLitMeta,
-                            &lit_min, &lit_max);
-        ok = sdec_init(L, 32 + hdr_nlit, hdr_ndist, kOffDistPrim, kSDistBits, kOffDistSorted,
-                       kOffDistMeta, &dist_min, &dist_max) && ok;
-        if (!ok) {
-          err = E_CORRUPT;
-        } else {
-          const int eob = (int)L.len_get(32 + 256);
-          if (lit_min < eob) lit_min = eob;  // :542-544
-          state = S_SYM;
-        }
-      } else {
-        const int x = shuff_sym(b, L, kOffDistPrim, kSDistBits, kOffDistSorted, kOffDistMeta, cl_min,
-                                cl_max, &err);
-        if (x >= 0) {
-          if (x < 16) {
-            L.len_set(32 + hdr_i, (uint32_t)x);
-            ++hdr_i;
-          } else {
-            int rep, nb;
-            uint32_t fill = 0;
-            bool bad = false;
-            if (x == 16) {
-              rep = 3;
-              nb = 2;
-              if (hdr_i == 0) bad = true; else fill = L.len_get(32 + hdr_i - 1);
-            } else if (x == 17) {
-              rep = 3;
-              nb = 3;
-            } else {
-              rep = 11;
-              nb = 7;
-            }
-            if (bad) {
-              err = E_CORRUPT;
-            } else if (!sbits_need(b, nb)) {
-              err = E_EOF;
-            } else {
-              rep += (int)((uint32_t)b.buf & ((1u << nb) - 1u));
-              sbits_drop(b, nb);
-              if (hdr_i + rep > hdr_n) {
-                err = E_CORRUPT;
-              } else {
-                for (int j = 0; j < rep; ++j) L.len_set(32 + hdr_i + j, fill);
-                hdr_i += rep;
-              }
-            }
-          }
-        }
-      }
-    } else if (state == S_SYM) {  // read_literal (:565-684)
-      const int v = shuff_sym(b, L, kOffLitPrim, kSPrimBits, kOffLitSorted, kOffLitMeta, lit_min, lit_max,
-                              &err);
-      if (v >= 0) {
-        if (v < 256) {
-          if (opos >= out_cap) {
-            err = E_OUT_SMALL;
-          } else {
-            out[opos++] = (uint8_t)v;
-          }
-        } else if (v == 256) {
-          state = S_BLOCK;  // finish_block
-        } else {
-          int length = 0, n = 0;
-          if (v < 265) {
-            length = v - (257 - 3);
-          } else if (v < 269) {
-            length = v * 2 - (265 * 2 - 11);
-            n = 1;
-          } else if (v < 273) {
-            length = v * 4 - (269 * 4 - 19);
-            n = 2;
-          } else if (v < 277) {
-            length = v * 8 - (273 * 8 - 35);
-            n = 3;
-          } else if (v < 281) {
-            length = v * 16 - (277 * 16 - 67);
-            n = 4;
-          } else if (v < 285) {
-            length = v * 32 - (281 * 32 - 131);
-            n = 5;
-          } else if (v < kMaxLit) {
-            length = 258;
-          } else {
-            err = E_CORRUPT;
-          }
-          if (!err && n > 0) {
-            if (!sbits_need(b, n)) {
-              err = E_EOF;
-            } else {
-              length += (int)((uint32_t)b.buf & ((1u << n) - 1u));
-              sbits_drop(b, n);
-            }
-          }
-          if (!err) {
-            int dist = shuff_sym(b, L, kOffDistPrim, kSDistBits, kOffDistSorted, kOffDistMeta, dist_min,
-                                 dist_max, &err);
-            if (dist >= 0) {
-              if (dist < 4) {
-                dist += 1;
-              } else if (dist < kMaxDist) {
-                const int nb = (dist - 2) >> 1;
-                int extra = (dist & 1) << nb;
-                if (!sbits_need(b, nb)) {
-                  err = E_EOF;
-                } else {
-                  extra |= (int)((uint32_t)b.buf & ((1u << nb) - 1u));
-                  sbits_drop(b, nb);
-                  dist = (1 << (nb + 1)) + 1 + extra;
-                }
-              } else {
-                err = E_CORRUPT;
-              }
-              if (!err) {
-                const uint32_t hist = opos < 32768u ? opos : 32768u;  // hist_size
-                if ((uint32_t)dist > hist) {
-                  err = E_CORRUPT;
-                } else if ((uint32_t)length > out_cap - opos) {
-                  err = E_OUT_SMALL;
-                } else {
-                  copy_len = (uint32_t)length;
-                  copy_dist = (uint32_t)dist;
-                  copy_fetch();
-                  state = S_COPY;
-                }
-              }
-            }
-          }
-        }
-      }
-    } else if (state == S_COPY) {  // copy_history (:689) / write_copy: up to 8 bytes per step
-      uint32_t k = copy_len < copy_dist ? copy_len : copy_dist;  // source bytes that already exist
-      if (k > 8u) k = 8u;
-      if (k == 8u) {
-        __builtin_memcpy(out + opos, &pend_lo, 4);
-        __builtin_memcpy(out + opos + 4, &pend_hi, 4);
-      } else {
-        const uint64_t v = ((uint64_t)pend_hi << 32) | pend_lo;
-        for (uint32_t i = 0; i < k; ++i) out[opos + i] = (uint8_t)(v >> (8 * i));
-      }
-      opos += k;
-      copy_len -= k;
-      if (copy_len == 0) state = S_SYM; else copy_fetch();
     } else if (state == S_STORED) {  // copy_data (:742-766): 8 raw bytes per step
       if (copy_len == 0) {
-        sbits_start(b, b.roff);  // restart the bit reader at the byte after the block
+        sb_start(b, sb_roffset(b));  // restart the bit reader at the byte after the block
         state = S_BLOCK;
       } else {
-        const uint32_t avail = b.in_len - b.roff;
-        uint32_t k = copy_len < 8u ? copy_len : 8u;
-        if (k > avail) k = avail;
-        if (k > out_cap - opos) {
+        const uint32_t p = sb_roffset(b);
+        const uint32_t avail = b.in_len - p;
+        uint32_t n = copy_len < 8u ? copy_len : 8u;
+        if (n > avail) n = avail;
+        if (n > out_cap - opos) {
           err = E_OUT_SMALL;
-        } else if (k == 0) {
+        } else if (n == 0) {
           err = E_EOF;
         } else {
-          for (uint32_t i = 0; i < k; ++i) out[opos + i] = b.in[b.roff + i];
-          opos += k;
-          b.roff += k;
-          copy_len -= k;
+          for (uint32_t i = 0; i < n; ++i) out[opos + i] = b.in[p + i];
+          opos += n;
+          b.hi = (p + n) * 8u;
+          copy_len -= n;
         }
       }
     }
-    if (err && state != S_DONE) state = S_DONE;
+    if (err) {
+      state = S_DONE;
+      if (k == 0) copy_len = 0;  // a raw-block count must not keep the lane alive
+    }
+
+    // (2) consume what the previous step requested (the only wait on global memory): advance the
+    // bit window, then the stores -- copy (copy_history :689 / write_copy), literal
+    const bool crossed = (b.bitpos >> 5) != b.widx;
+    if (crossed) {
+      b.w0 = b.w1;
+      b.w1 = b.nxt;
+      ++b.widx;
+    }
+    if (k != 0) {
+      uint8_t *dst = out + opos;
+      if (k == 8u) {
+        __builtin_memcpy(dst, &pend_lo, 4);
+        __builtin_memcpy(dst + 4, &pend_hi, 4);
+      } else {
+        uint32_t v = pend_lo;
+        if (k & 4u) {
+          __builtin_memcpy(dst, &v, 4);
+          dst += 4;
+          v = pend_hi;
+        }
+        if (k & 2u) {
+          const uint16_t h = (uint16_t)v;
+          __builtin_memcpy(dst, &h, 2);
+          dst += 2;
+          v >>= 16;
+        }
+        if (k & 1u) *dst = (uint8_t)v;
+      }
+      opos += k;
+      copy_len -= k;
+    }
+    if (lit_store) out[opos++] = (uint8_t)lit_val;
+    if (new_match) {
+      copy_len = match_len;
+      copy_dist = new_dist;
+    }
+    // (3) loads for the next step
+    if (crossed) b.nxt = sb_load(b, b.widx + 2);
+    if (state != S_STORED && copy_len != 0) {
+      const uint8_t *src = out + opos - copy_dist;
+      if (opos - copy_dist + 8u <= out_cap) {  // the 8-byte read stays inside this stream's slot
+        pend_lo = ld32g(src);
+        pend_hi = ld32g(src + 4);
+      } else {
+        uint32_t n = copy_len < copy_dist ? copy_len : copy_dist;
+        if (n > 8u) n = 8u;
+        uint64_t v = 0;
+        for (uint32_t i = 0; i < n; ++i) v |= (uint64_t)src[i] << (8 * i);
+        pend_lo = (uint32_t)v;
+        pend_hi = (uint32_t)(v >> 32);
+      }
+    }
   }
   if (have) {
     P.out_len[sid] = opos;
     P.status[sid] = err;
-    P.err_off[sid] = err == E_CORRUPT ? (long long)b.roff : -1;
+    P.err_off[sid] = err == E_CORRUPT ? (long long)sb_roffset(b) : -1;
   }
 }
 
