@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--no-guests", action="store_true",
                     help="match finder with LDS-table blocks only (no L2-table guest blocks); the "
                          "configuration the PMC traffic figure in profiles/ was collected on")
+    ap.add_argument("--inflate-lanes", type=int, default=0, choices=[0, 16, 32, 64],
+                    help="inflate: streams per wavefront (0 = chosen from the batch size)")
     ap.add_argument("--mode", default="deflate", choices=["deflate", "inflate"],
                     help="inflate = BASELINE.json configs[4]: decode the compressed streams (stream index supplied)")
     args = ap.parse_args()
@@ -96,6 +98,8 @@ def main():
     eng.set_profiling(True)
     if args.no_guests:
         eng.set_option("guest_blocks", 0)
+    if args.inflate_lanes:
+        eng.set_option("inflate_lanes", args.inflate_lanes)
     out = torch.empty(in_bytes + (in_bytes >> 3) + 4096, dtype=torch.uint8, device=dev)
 
     if args.mode == "inflate":

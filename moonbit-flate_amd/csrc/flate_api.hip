@@ -48,6 +48,8 @@ struct flate_hip_ctx {
   int guest_blocks = 0;      // 0 = guest kernel off
   float guest_share = 0.f;   // fraction of the single-window streams given to the guests
   uint32_t guest_min = 4096; // below this many streams the guests stay idle
+  uint32_t num_cus = 256;
+  int inflate_lanes = 0;  // streams per wavefront of that inflater: 0 = by batch size, or 16/32/64
   uint32_t inflate_simt_min = 2048;  // batches at least this large use the lane-per-stream inflater
   uint32_t resident_blocks = 1280;  // persistent LDS-table blocks (5 per CU x 256 CUs)
   uint32_t queue_init = 0;
@@ -322,6 +324,7 @@ int flate_hip_init(int device, flate_hip_ctx **out) {
     int cus = 256;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
       cus = prop.multiProcessorCount;
+    c->num_cus = (uint32_t)cus;
     c->resident_blocks = 5u * (uint32_t)cus;
     c->guest_blocks = 4 * cus;
   }
@@ -377,6 +380,8 @@ int flate_hip_set_option(flate_hip_ctx *c, const char *name, int64_t value) {
     c->guest_blocks = (int)value;
   } else if (k == "guest_min_streams" && value >= 0) {
     c->guest_min = (uint32_t)value;
+  } else if (k == "inflate_lanes" && (value == 0 || value == 16 || value == 32 || value == 64)) {
+    c->inflate_lanes = (int)value;
   } else if (k == "inflate_simt_min_streams" && value >= 0) {
     c->inflate_simt_min = (uint32_t)value;
   } else if (k == "resident_blocks" && value > 0 && value <= 65536) {
@@ -581,8 +586,17 @@ int flate_hip_inflate_batch(flate_hip_ctx *c, const uint8_t *in, const uint64_t 
     // (its bit positions are 32-bit: every compressed stream must be < 256 MiB)
     bool simt = n >= c->inflate_simt_min;
     for (uint32_t i = 0; i < n && simt; ++i) simt = in_off[i + 1] - in_off[i] < (1ull << 28);
-    if (simt)
-      hipLaunchKernelGGL(inflate_simt_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, I);
+    if (simt) {
+      // streams per wavefront: as many as still leave four wavefronts (one per SIMD) per CU
+      int lpw = c->inflate_lanes;
+      if (lpw == 0) lpw = n >= 256u * c->num_cus ? 64 : (n >= 128u * c->num_cus ? 32 : 16);
+      if (lpw == 64)
+        hipLaunchKernelGGL(inflate_simt_kernel<64>, dim3((n + 63) / 64), dim3(64), 0, c->stream, I);
+      else if (lpw == 32)
+        hipLaunchKernelGGL(inflate_simt_kernel<32>, dim3((n + 31) / 32), dim3(64), 0, c->stream, I);
+      else
+        hipLaunchKernelGGL(inflate_simt_kernel<16>, dim3((n + 15) / 16), dim3(64), 0, c->stream, I);
+    }
     else
       hipLaunchKernelGGL(inflate_kernel, dim3(n), dim3(64), 0, c->stream, I);
   }

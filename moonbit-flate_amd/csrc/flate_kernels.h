@@ -79,6 +79,7 @@ __global__ void huff_code_kernel(HuffParams P);
 __global__ void huff_pack_kernel(HuffParams P);
 __global__ void scan_sizes_kernel(CompactParams P);
 __global__ void inflate_kernel(InfParams P);
+template <int LPW>
 __global__ void inflate_simt_kernel(InfParams P);
 
 }  // namespace flate

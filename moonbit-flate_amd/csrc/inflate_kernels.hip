@@ -552,28 +552,33 @@ namespace flate {
 
 namespace {
 
-constexpr int kSPrimBits = 9, kSPrim = 1 << kSPrimBits;  // literal/length primary table
-constexpr int kSDistBits = 7, kSDist = 1 << kSDistBits;  // distance / code-length primary table
-// per-lane LDS layout, in u16 entries
-constexpr int kOffLitPrim = 0;
-constexpr int kOffDistPrim = kOffLitPrim + kSPrim;       // also the code-length decoder
-constexpr int kOffLitSorted = kOffDistPrim + kSDist;     // 288
-constexpr int kOffDistSorted = kOffLitSorted + 288;      // 32
-constexpr int kOffLitMeta = kOffDistSorted + 32;         // count[16] first[16] offs[16]
-constexpr int kOffDistMeta = kOffLitMeta + 48;
-constexpr int kOffLens = kOffDistMeta + 48;              // code lengths, two per u16
-constexpr int kLaneWords = kOffLens + 176;               // 352 lengths (32 + 286 + 30 used); 1232 u16 per lane
+// per-lane LDS layout, in u16 entries: 592 bytes per lane, so four 64-lane wavefronts fit one CU.
+// There is no lookup table: a code is resolved canonically (shuff_sym), which needs only the
+// symbols sorted by (length, symbol) -- one byte each -- and two small per-length arrays.
+constexpr int kOffLitSorted = 0;                      // 288 symbols & 0xff, two per u16
+constexpr int kOffDistSorted = kOffLitSorted + 144;   // 32 symbols (also the code-length decoder)
+constexpr int kOffLitMeta = kOffDistSorted + 16;      // delta[16], thr[16]
+constexpr int kOffDistMeta = kOffLitMeta + 32;        // delta[16]
+constexpr int kOffLens = kOffDistMeta + 16;           // 352 code lengths (32 + 286 + 30 used), four per u16
+constexpr int kLaneWords = kOffLens + 88;             // 296
 
 enum SState { S_BLOCK = 0, S_DYN_LENS, S_SYM, S_DIST, S_STORED, S_DONE };
 
+template <int LPW>
 struct LaneLds {
-  uint16_t *base;  // &lds[lane]
-  FLATE_D uint32_t get(int i) const { return base[i * 64]; }
-  FLATE_D void set(int i, uint32_t v) const { base[i * 64] = (uint16_t)v; }
-  FLATE_D uint32_t len_get(int i) const { return (base[(kOffLens + (i >> 1)) * 64] >> ((i & 1) * 8)) & 0xffu; }
+  uint16_t *base;  // &lds[lane]; entry i of this lane is base[i * LPW]
+  FLATE_D uint32_t get(int i) const { return base[i * LPW]; }
+  FLATE_D void set(int i, uint32_t v) const { base[i * LPW] = (uint16_t)v; }
+  FLATE_D uint32_t get8(int off, uint32_t i) const { return (base[(off + (int)(i >> 1)) * LPW] >> ((i & 1u) * 8u)) & 0xffu; }
+  FLATE_D void set8(int off, uint32_t i, uint32_t v) const {
+    uint16_t &w = base[(off + (int)(i >> 1)) * LPW];
+    w = (uint16_t)((i & 1u) ? ((w & 0x00ffu) | (v << 8)) : ((w & 0xff00u) | v));
+  }
+  FLATE_D uint32_t len_get(int i) const { return (base[(kOffLens + (i >> 2)) * LPW] >> ((i & 3) * 4)) & 15u; }
   FLATE_D void len_set(int i, uint32_t v) const {
-    uint16_t &w = base[(kOffLens + (i >> 1)) * 64];
-    w = (uint16_t)((i & 1) ? ((w & 0x00ffu) | (v << 8)) : ((w & 0xff00u) | v));
+    uint16_t &w = base[(kOffLens + (i >> 2)) * LPW];
+    const int sh = (i & 3) * 4;
+    w = (uint16_t)((w & ~(15u << sh)) | (v << sh));
   }
 };
 
@@ -626,115 +631,88 @@ FLATE_D void sb_sync(SBits &b) {
 }
 FLATE_D uint32_t sb_roffset(const SBits &b) { return (b.hi + 7u) >> 3; }
 
-// HuffmanDecoder::initialize for one lane: lens[lens_at .. +n) -> primary table + canonical arrays.
-// Returns false for an over/under-subscribed code (inflate.mbt:161); *mn/*mx = min/max length.
-// lim[k - prim_bits - 1] (k = prim_bits+1 .. 15) = exclusive upper bound of the codes of length <= k,
-// left-justified to 15 bits: the loop-free length search of shuff_sym.  meta+16+l holds
-// offs[l] - first[l] (mod 2^16), so sorted index = code + that.
-template <int NLIM>
-FLATE_D bool sdec_init(const LaneLds &L, int lens_at, int n, int prim_off, int prim_bits, int sorted_off,
-                       int meta_off, int *mn_out, int *mx_out, uint32_t (&lim)[NLIM]) {
+// HuffmanDecoder::initialize for one lane (inflate.mbt:118-213): lens[lens_at .. +n) -> the
+// canonical decoding data.  Returns false for an over/under-subscribed code (:161); *mn = min
+// length.  lim[k-1] (k = 1..15) = exclusive upper bound of the codes of length <= k, left-justified
+// to 15 bits; meta[k] = offs[k] - first[k] (mod 2^16), so sorted index = code + meta[k]; with THR,
+// meta[16+k] = first code of length k whose symbol is >= 256 (the sorted list keeps only the low
+// byte; inside one length symbols ascend, so those come last).
+template <bool THR, class LL>
+FLATE_D bool sdec_init(const LL &L, int lens_at, int n, int sorted_off, int meta_off, int *mn_out,
+                       uint32_t (&lim)[15]) {
+  uint32_t cnt[16], low[16];
 #pragma unroll
-  for (int k = 0; k < NLIM; ++k) lim[k] = 0;
-  const int psize = 1 << prim_bits;
-  for (int i = 0; i < psize; ++i) L.set(prim_off + i, 0);
-  for (int l = 0; l < 16; ++l) L.set(meta_off + l, 0);
+  for (int k = 0; k < 16; ++k) cnt[k] = low[k] = 0;
   for (int i = 0; i < n; ++i) {
     const uint32_t l = L.len_get(lens_at + i);
-    if (l) L.set(meta_off + l, L.get(meta_off + l) + 1);
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+      cnt[k] += l == (uint32_t)k ? 1u : 0u;
+      if (THR) low[k] += (l == (uint32_t)k && i < 256) ? 1u : 0u;
+    }
   }
   int mn = 0, mx = 0;
-  for (int l = 1; l < 16; ++l)
-    if (L.get(meta_off + l)) {
-      if (!mn) mn = l;
-      mx = l;
-    }
+#pragma unroll
+  for (int k = 15; k >= 1; --k) {
+    if (cnt[k]) mn = k;
+    if (cnt[k] && !mx) mx = k;
+  }
   *mn_out = mn;
-  *mx_out = mx;
-  if (mx == 0) return true;  // empty tree (:143-145)
+#pragma unroll
+  for (int k = 0; k < 15; ++k) lim[k] = 0;
+  if (mx == 0) return true;  // empty tree (:143-145): every lookup is corrupt
+  uint32_t next_off[16];
   uint32_t code = 0, off = 0;
-  for (int l = 1; l < 16; ++l) {
+#pragma unroll
+  for (int k = 1; k < 16; ++k) {  // :148-154
     code <<= 1;
-    const uint32_t c = L.get(meta_off + l);
-    L.set(meta_off + 16 + l, (off - code) & 0xffffu);  // offs[l] - first[l]
-    code += c;
-    off += c;
+    L.set(meta_off + k, (off - code) & 0xffffu);
+    if (THR) L.set(meta_off + 16 + k, code + low[k]);
+    next_off[k] = off;
+    code += cnt[k];
+    off += cnt[k];
+    lim[k - 1] = code << (15 - k);
   }
-  // completeness (:161): recompute as the reference does, from min to max
-  {
+  {  // completeness (:161), from min to max as the reference computes it
     uint32_t cc = 0;
-    for (int l = mn; l <= mx; ++l) cc = (cc << 1) + L.get(meta_off + l);
+#pragma unroll
+    for (int k = 1; k < 16; ++k)
+      if (k >= mn && k <= mx) cc = (cc << 1) + cnt[k];
     if (cc != (1u << mx) && !(cc == 1 && mx == 1)) return false;
-  }
-  // canonical assignment in symbol order; the running code/offset per length live in registers
-  uint32_t next_code[16], next_off[16];
-#pragma unroll
-  for (int l = 0; l < 16; ++l) {
-    next_code[l] = 0;
-    next_off[l] = 0;
-  }
-  {
-    uint32_t c2 = 0, o2 = 0;
-#pragma unroll
-    for (int l = 1; l < 16; ++l) {
-      c2 <<= 1;
-      const uint32_t c = L.get(meta_off + l);
-      next_code[l] = c2;
-      c2 += c;
-      next_off[l] = o2;
-      o2 += c;
-      if (l > prim_bits && l - prim_bits - 1 < NLIM) lim[l - prim_bits - 1] = c2 << (15 - l);
-    }
   }
   for (int i = 0; i < n; ++i) {
     const uint32_t l = L.len_get(lens_at + i);
     if (!l) continue;
-    uint32_t code_i = 0, off_i = 0;
+    uint32_t at = 0;
 #pragma unroll
     for (int k = 1; k < 16; ++k)
-      if (l == (uint32_t)k) {
-        code_i = next_code[k]++;
-        off_i = next_off[k]++;
-      }
-    L.set(sorted_off + off_i, (uint32_t)i);
-    if ((int)l <= prim_bits) {
-      const uint32_t rev = __brev(code_i) >> (32 - l);
-      const uint32_t e = ((uint32_t)i << 4) | l;
-      for (uint32_t k = rev; k < (uint32_t)psize; k += 1u << l) L.set(prim_off + k, e);
-    } else {
-      const uint32_t top = code_i >> (l - prim_bits);
-      L.set(prim_off + (__brev(top) >> (32 - prim_bits)), kLongCode);
-    }
+      if (l == (uint32_t)k) at = next_off[k]++;
+    L.set8(sorted_off, at, (uint32_t)i & 0xffu);
   }
   return true;
 }
 
-// huff_sym for one lane (inflate.mbt:803-854); never loads (see the step loop).  Codes longer than
-// the primary table are resolved without a loop: the code length is the number of limits the
-// next 15 bits (MSB first) reach, the symbol sits at code + (offs - first) in the sorted list.
-// Returns the symbol, or -1 with *err set.
-template <int NLIM>
-FLATE_D int shuff_sym(SBits &b, const LaneLds &L, int prim_off, int prim_bits, int sorted_off, int meta_off,
-                      int dmin, const uint32_t (&lim)[NLIM], int *err) {
-  const uint32_t w = sb_peek(b);
-  const uint32_t e = L.get(prim_off + (int)(w & ((1u << prim_bits) - 1u)));
+// huff_sym for one lane (inflate.mbt:803-854); never loads (see the step loop).  Canonical, without
+// a loop: the code length is 1 + the number of limits the next 15 bits (MSB first) reach; the
+// symbol sits at code + (offs - first) in the sorted list.  Returns the symbol, or -1 with *err set.
+template <bool THR, class LL>
+FLATE_D int shuff_sym(SBits &b, const LL &L, int sorted_off, int meta_off, int dmin, const uint32_t (&lim)[15],
+                      int *err) {
+  const uint32_t c15 = __brev(sb_peek(b)) >> 17;
   if (!sb_need(b, (uint32_t)dmin)) {
     *err = E_EOF;
     return -1;
   }
-  uint32_t len = e & 15u, sym = e >> 4;
-  if (e == kLongCode) {
-    const uint32_t c15 = __brev(w) >> 17;
-    len = (uint32_t)prim_bits + 1u;
+  uint32_t len = 1;
 #pragma unroll
-    for (int k = 0; k < NLIM; ++k) len += c15 >= lim[k] ? 1u : 0u;
-    if (len > 15u) len = 0;  // no code: corrupt
-    else sym = L.get(sorted_off + (int)(((c15 >> (15u - len)) + L.get(meta_off + 16 + (int)len)) & 0xffffu));
-  }
-  if (len == 0) {  // e == 0: unused primary slot
+  for (int k = 0; k < 15; ++k) len += c15 >= lim[k] ? 1u : 0u;
+  if (len > 15u) {  // no such code (also: empty tree)
     *err = E_CORRUPT;
     return -1;
   }
+  const uint32_t code = c15 >> (15u - len);
+  uint32_t sym = L.get8(sorted_off, (code + L.get(meta_off + (int)len)) & 0xffffu);
+  if (THR) sym |= code >= L.get(meta_off + 16 + (int)len) ? 256u : 0u;
   if (!sb_need(b, len)) {
     *err = E_EOF;
     return -1;
@@ -745,12 +723,16 @@ FLATE_D int shuff_sym(SBits &b, const LaneLds &L, int prim_off, int prim_bits, i
 
 }  // namespace
 
+// LPW = streams (active lanes) per wavefront.  The tables of 64 lanes fill the LDS of a CU, so a
+// batch that cannot give every CU 64 streams per SIMD runs with 32 or 16 lanes per wavefront and
+// 2 or 4 wavefronts per CU instead: the step time is latency, not lane count.
+template <int LPW>
 __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
-  __shared__ uint16_t lds[kLaneWords * 64];
+  __shared__ uint16_t lds[kLaneWords * LPW];
   const int lane = threadIdx.x;
-  const uint32_t sid = blockIdx.x * 64u + (uint32_t)lane;
-  const bool have = sid < P.n_streams;
-  const LaneLds L = {lds + lane};
+  const uint32_t sid = blockIdx.x * (uint32_t)LPW + (uint32_t)lane;
+  const bool have = lane < LPW && sid < P.n_streams;
+  const LaneLds<LPW> L = {lds + (lane < LPW ? lane : 0)};
 
   SBits b;
   uint8_t *out = P.out;
@@ -772,9 +754,9 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
   int state = have ? S_BLOCK : S_DONE;
   int err = 0;
   bool final_block = false;
-  int lit_min = 0, lit_max = 0, dist_min = 0, dist_max = 0, cl_min = 0, cl_max = 0;
+  int lit_min = 0, dist_min = 0, cl_min = 0;
   int hdr_i = 0, hdr_n = 0, hdr_nlit = 0, hdr_ndist = 0;
-  uint32_t lit_lim[15 - kSPrimBits], dist_lim[15 - kSDistBits];  // see shuff_sym
+  uint32_t lit_lim[15], dist_lim[15];    // see shuff_sym; dist_lim also serves the code-length code
   uint32_t match_len = 0;                // S_DIST: the length decoded by S_SYM
   uint32_t copy_len = 0, copy_dist = 0;  // LZ77 copy in flight (S_STORED: raw bytes left in copy_len)
   uint32_t pend_lo = 0, pend_hi = 0;     // its next (up to) 8 source bytes, requested a step ahead
@@ -800,8 +782,7 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
     uint32_t lit_val = 0, new_dist = 0;
 
     if (state == S_SYM && last_chunk) {  // read_literal (:565-630): literal/length symbol + extra
-      const int v = shuff_sym(b, L, kOffLitPrim, kSPrimBits, kOffLitSorted, kOffLitMeta, lit_min, lit_lim,
-                              &err);
+      const int v = shuff_sym<true>(b, L, kOffLitSorted, kOffLitMeta, lit_min, lit_lim, &err);
       if (v >= 0) {
         if (v < 256) {
           lit_store = opos_eff < out_cap;
@@ -833,8 +814,7 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
         }
       }
     } else if (state == S_DIST && last_chunk) {  // read_literal (:631-684): distance symbol + extra
-      const int d = shuff_sym(b, L, kOffDistPrim, kSDistBits, kOffDistSorted, kOffDistMeta, dist_min,
-                              dist_lim, &err);
+      const int d = shuff_sym<false>(b, L, kOffDistSorted, kOffDistMeta, dist_min, dist_lim, &err);
       if (d >= 0) {
         if (d >= kMaxDist) {
           err = E_CORRUPT;
@@ -862,12 +842,8 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
       }
     } else if (state == S_DYN_LENS && copy_len == 0) {  // :471-536, one code-length symbol per step
       if (hdr_i >= hdr_n) {
-        // the code-length decoder sits in the distance slots: build literal first (it only
-        // reads lens), then distance
-        bool ok = sdec_init(L, 32, hdr_nlit, kOffLitPrim, kSPrimBits, kOffLitSorted, kOffLitMeta,
-                            &lit_min, &lit_max, lit_lim);
-        ok = sdec_init(L, 32 + hdr_nlit, hdr_ndist, kOffDistPrim, kSDistBits, kOffDistSorted,
-                       kOffDistMeta, &dist_min, &dist_max, dist_lim) && ok;
+        bool ok = sdec_init<true>(L, 32, hdr_nlit, kOffLitSorted, kOffLitMeta, &lit_min, lit_lim);
+        ok = sdec_init<false>(L, 32 + hdr_nlit, hdr_ndist, kOffDistSorted, kOffDistMeta, &dist_min, dist_lim) && ok;
         if (!ok) {
           err = E_CORRUPT;
         } else {
@@ -876,8 +852,7 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
           state = S_SYM;
         }
       } else {
-        const int x = shuff_sym(b, L, kOffDistPrim, kSDistBits, kOffDistSorted, kOffDistMeta, cl_min,
-                                dist_lim, &err);
+        const int x = shuff_sym<false>(b, L, kOffDistSorted, kOffDistMeta, cl_min, dist_lim, &err);
         if (x >= 0) {
           if (x < 16) {
             L.len_set(32 + hdr_i, (uint32_t)x);
@@ -939,10 +914,8 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
         } else if (typ == 1) {  // fixed tables (:886-939); distances are 5-bit codes
           for (int i = 0; i < 288; ++i) L.len_set(i, i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8)));
           for (int i = 0; i < 32; ++i) L.len_set(288 + i, 5);
-          sdec_init(L, 0, 288, kOffLitPrim, kSPrimBits, kOffLitSorted, kOffLitMeta, &lit_min, &lit_max,
-                    lit_lim);
-          sdec_init(L, 288, 32, kOffDistPrim, kSDistBits, kOffDistSorted, kOffDistMeta, &dist_min, &dist_max,
-                    dist_lim);
+          sdec_init<true>(L, 0, 288, kOffLitSorted, kOffLitMeta, &lit_min, lit_lim);
+          sdec_init<false>(L, 288, 32, kOffDistSorted, kOffDistMeta, &dist_min, dist_lim);
           state = S_SYM;
         } else {  // read_huffman (:429-470)
           if (!sb_need(b, 14)) {
@@ -968,8 +941,7 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
                 }
               }
               if (!err) {
-                if (!sdec_init(L, 0, kNumCodes, kOffDistPrim, kSDistBits, kOffDistSorted, kOffDistMeta,
-                               &cl_min, &cl_max, dist_lim)) {
+                if (!sdec_init<false>(L, 0, kNumCodes, kOffDistSorted, kOffDistMeta, &cl_min, dist_lim)) {
                   err = E_CORRUPT;
                 } else {
                   hdr_i = 0;
@@ -1045,6 +1017,7 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
     }
     // (3) loads for the next step
     if (crossed) b.nxt = sb_load(b, b.widx + 2);
+#ifndef FLATE_EXP_NO_HISTORY_READ
     if (state != S_STORED && copy_len != 0) {
       const uint8_t *src = out + opos - copy_dist;
       if (opos - copy_dist + 8u <= out_cap) {  // the 8-byte read stays inside this stream's slot
@@ -1059,6 +1032,7 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
         pend_hi = (uint32_t)(v >> 32);
       }
     }
+#endif
   }
   if (have) {
     P.out_len[sid] = opos;
@@ -1066,5 +1040,8 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
     P.err_off[sid] = err == E_CORRUPT ? (long long)sb_roffset(b) : -1;
   }
 }
+template __global__ void inflate_simt_kernel<64>(InfParams);
+template __global__ void inflate_simt_kernel<32>(InfParams);
+template __global__ void inflate_simt_kernel<16>(InfParams);
 
 }  // namespace flate
