@@ -591,11 +591,11 @@ int flate_hip_inflate_batch(flate_hip_ctx *c, const uint8_t *in, const uint64_t 
       int lpw = c->inflate_lanes;
       if (lpw == 0) lpw = n >= 256u * c->num_cus ? 64 : (n >= 128u * c->num_cus ? 32 : 16);
       if (lpw == 64)
-        hipLaunchKernelGGL(inflate_simt_kernel<64>, dim3((n + 63) / 64), dim3(64), 0, c->stream, I);
+        hipLaunchKernelGGL(inflate_simt_kernel<64>, dim3((n + 63) / 64), dim3(64), inflate_simt_lds_bytes(64), c->stream, I);
       else if (lpw == 32)
-        hipLaunchKernelGGL(inflate_simt_kernel<32>, dim3((n + 31) / 32), dim3(64), 0, c->stream, I);
+        hipLaunchKernelGGL(inflate_simt_kernel<32>, dim3((n + 31) / 32), dim3(64), inflate_simt_lds_bytes(32), c->stream, I);
       else
-        hipLaunchKernelGGL(inflate_simt_kernel<16>, dim3((n + 15) / 16), dim3(64), 0, c->stream, I);
+        hipLaunchKernelGGL(inflate_simt_kernel<16>, dim3((n + 15) / 16), dim3(64), inflate_simt_lds_bytes(16), c->stream, I);
     }
     else
       hipLaunchKernelGGL(inflate_kernel, dim3(n), dim3(64), 0, c->stream, I);

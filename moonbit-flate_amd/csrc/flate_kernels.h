@@ -81,5 +81,6 @@ __global__ void scan_sizes_kernel(CompactParams P);
 __global__ void inflate_kernel(InfParams P);
 template <int LPW>
 __global__ void inflate_simt_kernel(InfParams P);
+size_t inflate_simt_lds_bytes(int lanes_per_wave);  // dynamic LDS of that launch
 
 }  // namespace flate

@@ -563,6 +563,13 @@ constexpr int kOffLens = kOffDistMeta + 16;           // 352 code lengths (32 + 
 constexpr int kLaneWords = kOffLens + 88;             // 296
 
 enum SState { S_BLOCK = 0, S_DYN_LENS, S_SYM, S_DIST, S_STORED, S_DONE };
+constexpr int kSymPerStep = 3;  // literal/length symbols one lane may decode per step
+
+// The 15 code-length limits of one Huffman code, two per register (see shuff_sym).
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+struct Limits {
+  us2 p[8];
+};
 
 template <int LPW>
 struct LaneLds {
@@ -603,12 +610,18 @@ FLATE_D uint32_t sb_load(const SBits &b, uint32_t widx) {
   }
   return w;
 }
+// s_waitcnt vmcnt(0) (gfx9 encoding: vmcnt 0, expcnt/lgkmcnt untouched).  The block-header paths
+// load straight into the window registers; waiting there keeps the compiler from guarding every
+// use of the window in the hot states with a wait that would also cover the prefetches.
+FLATE_D void vm_wait_all() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
 FLATE_D void sb_start(SBits &b, uint32_t byte_pos) {
   b.bitpos = b.hi = byte_pos * 8u;
   b.widx = byte_pos >> 2;
   b.w0 = sb_load(b, b.widx);
   b.w1 = sb_load(b, b.widx + 1);
   b.nxt = sb_load(b, b.widx + 2);
+  vm_wait_all();
 }
 // the next 32 bits; valid while bitpos is inside w0/w1, i.e. after <= 32 bits taken since a sync
 FLATE_D uint32_t sb_peek(const SBits &b) {
@@ -627,6 +640,7 @@ FLATE_D void sb_sync(SBits &b) {
     b.w1 = b.nxt;
     ++b.widx;
     b.nxt = sb_load(b, b.widx + 2);
+    vm_wait_all();
   }
 }
 FLATE_D uint32_t sb_roffset(const SBits &b) { return (b.hi + 7u) >> 3; }
@@ -639,7 +653,8 @@ FLATE_D uint32_t sb_roffset(const SBits &b) { return (b.hi + 7u) >> 3; }
 // byte; inside one length symbols ascend, so those come last).
 template <bool THR, class LL>
 FLATE_D bool sdec_init(const LL &L, int lens_at, int n, int sorted_off, int meta_off, int *mn_out,
-                       uint32_t (&lim)[15]) {
+                       Limits &lim_out) {
+  uint32_t lim[16];
   uint32_t cnt[16], low[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) cnt[k] = low[k] = 0;
@@ -659,8 +674,9 @@ FLATE_D bool sdec_init(const LL &L, int lens_at, int n, int sorted_off, int meta
   }
   *mn_out = mn;
 #pragma unroll
-  for (int k = 0; k < 15; ++k) lim[k] = 0;
+  for (int k = 0; k < 8; ++k) lim_out.p[k] = us2{0, 0};
   if (mx == 0) return true;  // empty tree (:143-145): every lookup is corrupt
+  lim[15] = 0;  // pad: never above the code bits
   uint32_t next_off[16];
   uint32_t code = 0, off = 0;
 #pragma unroll
@@ -680,6 +696,8 @@ FLATE_D bool sdec_init(const LL &L, int lens_at, int n, int sorted_off, int meta
       if (k >= mn && k <= mx) cc = (cc << 1) + cnt[k];
     if (cc != (1u << mx) && !(cc == 1 && mx == 1)) return false;
   }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) lim_out.p[k] = us2{(unsigned short)lim[2 * k], (unsigned short)lim[2 * k + 1]};
   for (int i = 0; i < n; ++i) {
     const uint32_t l = L.len_get(lens_at + i);
     if (!l) continue;
@@ -692,27 +710,42 @@ FLATE_D bool sdec_init(const LL &L, int lens_at, int n, int sorted_off, int meta
   return true;
 }
 
-// huff_sym for one lane (inflate.mbt:803-854); never loads (see the step loop).  Canonical, without
-// a loop: the code length is 1 + the number of limits the next 15 bits (MSB first) reach; the
-// symbol sits at code + (offs - first) in the sorted list.  Returns the symbol, or -1 with *err set.
+// Canonical decode of one code, no loop and no branch: returns the code length (16 = no such
+// code, also for an empty tree) and the symbol.  The length is 16 - the number of limits above the
+// next 15 bits (MSB first), counted two at a time with packed 16-bit arithmetic (c15 - lim is
+// negative exactly when lim is above); the symbol sits at code + (offs - first) in the sorted
+// list.  w = the bit window (LSB = next bit).
 template <bool THR, class LL>
-FLATE_D int shuff_sym(SBits &b, const LL &L, int sorted_off, int meta_off, int dmin, const uint32_t (&lim)[15],
-                      int *err) {
-  const uint32_t c15 = __brev(sb_peek(b)) >> 17;
+FLATE_D uint32_t canon_decode(const LL &L, uint32_t w, int sorted_off, int meta_off, const Limits &lim,
+                              uint32_t *sym_out) {
+  const uint32_t c15 = __brev(w) >> 17;
+  const us2 c2 = us2{(unsigned short)c15, (unsigned short)c15};
+  us2 above = us2{0, 0};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) above += (c2 - lim.p[k]) >> 15;
+  const uint32_t len = 16u - above.x - above.y;
+  const uint32_t lc = len > 15u ? 15u : len;
+  const uint32_t code = c15 >> (15u - lc);
+  uint32_t sym = L.get8(sorted_off, (code + L.get(meta_off + (int)lc)) & 0xffffu);
+  if (THR) sym |= code >= L.get(meta_off + 16 + (int)lc) ? 256u : 0u;
+  *sym_out = sym;
+  return len;
+}
+
+// huff_sym (inflate.mbt:803-854) for the block-header states; the hot states inline the same
+// checks without branches.  Returns the symbol, or -1 with *err set.
+template <class LL>
+FLATE_D int shuff_sym(SBits &b, const LL &L, int sorted_off, int meta_off, int dmin, const Limits &lim, int *err) {
+  uint32_t sym;
+  const uint32_t len = canon_decode<false>(L, sb_peek(b), sorted_off, meta_off, lim, &sym);
   if (!sb_need(b, (uint32_t)dmin)) {
     *err = E_EOF;
     return -1;
   }
-  uint32_t len = 1;
-#pragma unroll
-  for (int k = 0; k < 15; ++k) len += c15 >= lim[k] ? 1u : 0u;
-  if (len > 15u) {  // no such code (also: empty tree)
+  if (len > 15u) {
     *err = E_CORRUPT;
     return -1;
   }
-  const uint32_t code = c15 >> (15u - len);
-  uint32_t sym = L.get8(sorted_off, (code + L.get(meta_off + (int)len)) & 0xffffu);
-  if (THR) sym |= code >= L.get(meta_off + 16 + (int)len) ? 256u : 0u;
   if (!sb_need(b, len)) {
     *err = E_EOF;
     return -1;
@@ -721,28 +754,198 @@ FLATE_D int shuff_sym(SBits &b, const LL &L, int sorted_off, int meta_off, int d
   return (int)sym;
 }
 
+// Everything one lane carries between steps.
+struct Lane {
+  SBits b;
+  uint8_t *out;
+  uint32_t out_cap, opos;
+  int state, err;
+  bool final_block;
+  int lit_min, dist_min, cl_min;
+  int hdr_i, hdr_n, hdr_nlit, hdr_ndist;
+  Limits lit_lim, dist_lim;        // dist_lim also serves the code-length code
+  uint32_t match_len;              // S_DIST: the length decoded by S_SYM
+  uint32_t copy_len, copy_dist;    // LZ77 copy in flight (S_STORED: raw bytes left, in copy_len)
+  uint32_t pend_lo, pend_hi;       // its next (up to) 8 source bytes, requested a step ahead
+  uint32_t lit_acc, lit_n;         // literals decoded but not stored yet (they end at opos)
+};
+
+extern __shared__ uint16_t simt_lds[];  // kLaneWords * LPW entries
+
+// One step of a lane in S_BLOCK, S_DYN_LENS or S_STORED: block headers, table construction, raw
+// blocks.  Out of line: these are a few hundred steps per block against tens of thousands of
+// symbol steps, and keeping them out of the step loop keeps that loop small.  Loads here block.
+template <int LPW>
+__attribute__((noinline)) FLATE_D void slow_step(Lane &ln, int lane) {
+  const LaneLds<LPW> L = {simt_lds + lane};
+  SBits &b = ln.b;
+  int err = 0;
+  if (ln.state == S_DYN_LENS) {  // inflate.mbt:471-536, one code-length symbol per step
+    if (ln.hdr_i >= ln.hdr_n) {
+      // (the code-length decoder sits in the distance slots: the literal code is built first)
+      bool ok = sdec_init<true>(L, 32, ln.hdr_nlit, kOffLitSorted, kOffLitMeta, &ln.lit_min, ln.lit_lim);
+      ok = sdec_init<false>(L, 32 + ln.hdr_nlit, ln.hdr_ndist, kOffDistSorted, kOffDistMeta, &ln.dist_min,
+                            ln.dist_lim) && ok;
+      if (!ok) {
+        err = E_CORRUPT;
+      } else {
+        const int eob = (int)L.len_get(32 + 256);
+        if (ln.lit_min < eob) ln.lit_min = eob;  // :542-544
+        ln.state = S_SYM;
+      }
+    } else {
+      sb_sync(b);
+      const int x = shuff_sym(b, L, kOffDistSorted, kOffDistMeta, ln.cl_min, ln.dist_lim, &err);
+      if (x >= 0) {
+        if (x < 16) {
+          L.len_set(32 + ln.hdr_i, (uint32_t)x);
+          ++ln.hdr_i;
+        } else {
+          int rep = x == 18 ? 11 : 3;
+          const uint32_t nb = x == 16 ? 2u : (x == 17 ? 3u : 7u);
+          uint32_t fill = 0;
+          if (x == 16 && ln.hdr_i == 0) {
+            err = E_CORRUPT;
+          } else {
+            if (x == 16) fill = L.len_get(32 + ln.hdr_i - 1);
+            const uint32_t w = sb_peek(b);
+            if (!sb_need(b, nb)) {
+              err = E_EOF;
+            } else {
+              sb_take(b, nb);
+              rep += (int)(w & ((1u << nb) - 1u));
+              if (ln.hdr_i + rep > ln.hdr_n) {
+                err = E_CORRUPT;
+              } else {
+                for (int j = 0; j < rep; ++j) L.len_set(32 + ln.hdr_i + j, fill);
+                ln.hdr_i += rep;
+              }
+            }
+          }
+        }
+      }
+    }
+  } else if (ln.state == S_BLOCK) {  // next_block (inflate.mbt:345-379)
+    sb_sync(b);
+    if (ln.final_block) {
+      ln.state = S_DONE;
+    } else if (!sb_need(b, 3)) {
+      err = E_EOF;
+    } else {
+      const uint32_t h = sb_peek(b) & 7u;
+      ln.final_block = h & 1;
+      const uint32_t typ = h >> 1;
+      sb_take(b, 3);
+      if (typ == 3) {
+        err = E_CORRUPT;
+      } else if (typ == 0) {  // data_block (:708-737): header bytes follow the bytes read so far
+        const uint32_t p = sb_roffset(b);
+        if (b.in_len - p < 4) {
+          b.hi = b.in_bits;
+          err = E_EOF;
+        } else {
+          b.hi = (p + 4) * 8u;
+          const uint32_t n = (uint32_t)b.in[p] | ((uint32_t)b.in[p + 1] << 8);
+          const uint32_t nn = (uint32_t)b.in[p + 2] | ((uint32_t)b.in[p + 3] << 8);
+          if ((nn & 0xffffu) != ((~n) & 0xffffu)) {
+            err = E_CORRUPT;
+          } else {
+            ln.copy_len = n;
+            ln.state = S_STORED;
+          }
+        }
+      } else if (typ == 1) {  // fixed tables (:886-939); distances are 5-bit codes
+        for (int i = 0; i < 288; ++i) L.len_set(i, i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8)));
+        for (int i = 0; i < 32; ++i) L.len_set(288 + i, 5);
+        sdec_init<true>(L, 0, 288, kOffLitSorted, kOffLitMeta, &ln.lit_min, ln.lit_lim);
+        sdec_init<false>(L, 288, 32, kOffDistSorted, kOffDistMeta, &ln.dist_min, ln.dist_lim);
+        ln.state = S_SYM;
+      } else if (!sb_need(b, 14)) {  // read_huffman (:429-470)
+        err = E_EOF;
+      } else {
+        const uint32_t v = sb_peek(b) & 0x3fffu;
+        ln.hdr_nlit = (int)(v & 31u) + 257;
+        ln.hdr_ndist = (int)((v >> 5) & 31u) + 1;
+        const int nclen = (int)((v >> 10) & 15u) + 4;
+        if (ln.hdr_nlit > kMaxLit || ln.hdr_ndist > kMaxDist) {
+          err = E_CORRUPT;
+        } else {
+          sb_take(b, 14);
+          sb_sync(b);
+          for (int i = 0; i < kNumCodes; ++i) L.len_set(i, 0);
+          for (int i = 0; i < nclen && !err; ++i) {
+            if (!sb_need(b, 3)) {
+              err = E_EOF;
+            } else {
+              L.len_set(kCodeOrder[i], sb_peek(b) & 7u);
+              sb_take(b, 3);
+              sb_sync(b);
+            }
+          }
+          if (!err) {
+            if (!sdec_init<false>(L, 0, kNumCodes, kOffDistSorted, kOffDistMeta, &ln.cl_min, ln.dist_lim)) {
+              err = E_CORRUPT;
+            } else {
+              ln.hdr_i = 0;
+              ln.hdr_n = ln.hdr_nlit + ln.hdr_ndist;
+              ln.state = S_DYN_LENS;
+            }
+          }
+        }
+      }
+    }
+    sb_sync(b);
+  } else if (ln.state == S_STORED) {  // copy_data (:742-766): 8 raw bytes per step
+    if (ln.copy_len == 0) {
+      sb_start(b, sb_roffset(b));  // restart the bit reader at the byte after the block
+      ln.state = S_BLOCK;
+    } else {
+      const uint32_t p = sb_roffset(b);
+      const uint32_t avail = b.in_len - p;
+      uint32_t n = ln.copy_len < 8u ? ln.copy_len : 8u;
+      if (n > avail) n = avail;
+      if (n > ln.out_cap - ln.opos) {
+        err = E_OUT_SMALL;
+      } else if (n == 0) {
+        err = E_EOF;
+      } else {
+        for (uint32_t i = 0; i < n; ++i) ln.out[ln.opos + i] = b.in[p + i];
+        ln.opos += n;
+        b.hi = (p + n) * 8u;
+        ln.copy_len -= n;
+      }
+    }
+  }
+  if (err) {
+    ln.err = err;
+    ln.state = S_DONE;
+    ln.copy_len = 0;  // a raw-block count must not keep the lane alive
+  }
+  vm_wait_all();
+}
+
 }  // namespace
 
-// LPW = streams (active lanes) per wavefront.  The tables of 64 lanes fill the LDS of a CU, so a
-// batch that cannot give every CU 64 streams per SIMD runs with 32 or 16 lanes per wavefront and
-// 2 or 4 wavefronts per CU instead: the step time is latency, not lane count.
+// LPW = streams (active lanes) per wavefront; four 64-lane wavefronts fit the LDS of a CU, and a
+// batch too small to give every SIMD one of those runs with 32 or 16 lanes per wavefront.
 template <int LPW>
 __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
-  __shared__ uint16_t lds[kLaneWords * LPW];
   const int lane = threadIdx.x;
+  const int lds_lane = lane < LPW ? lane : 0;
   const uint32_t sid = blockIdx.x * (uint32_t)LPW + (uint32_t)lane;
   const bool have = lane < LPW && sid < P.n_streams;
-  const LaneLds<LPW> L = {lds + (lane < LPW ? lane : 0)};
+  const LaneLds<LPW> L = {simt_lds + lds_lane};
 
-  SBits b;
-  uint8_t *out = P.out;
-  uint32_t out_cap = 0;
+  Lane ln;
+  SBits &b = ln.b;
+  ln.out = P.out;
+  ln.out_cap = 0;
   b.in = P.in;
   b.in_len = 0;
   if (have) {
-    out = P.out + P.out_off[sid];
+    ln.out = P.out + P.out_off[sid];
     const uint64_t cap64 = P.out_off[sid + 1] - P.out_off[sid];
-    out_cap = cap64 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)cap64;
+    ln.out_cap = cap64 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)cap64;
     b.in = P.in + P.in_off[sid];
     b.in_len = (uint32_t)(P.in_off[sid + 1] - P.in_off[sid]);  // < 2^28: checked by the host
   }
@@ -750,254 +953,152 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
   b.bitpos = b.hi = b.widx = 0;
   b.w0 = b.w1 = b.nxt = 0;
   if (have) sb_start(b, 0);
-  uint32_t opos = 0;
-  int state = have ? S_BLOCK : S_DONE;
-  int err = 0;
-  bool final_block = false;
-  int lit_min = 0, dist_min = 0, cl_min = 0;
-  int hdr_i = 0, hdr_n = 0, hdr_nlit = 0, hdr_ndist = 0;
-  uint32_t lit_lim[15], dist_lim[15];    // see shuff_sym; dist_lim also serves the code-length code
-  uint32_t match_len = 0;                // S_DIST: the length decoded by S_SYM
-  uint32_t copy_len = 0, copy_dist = 0;  // LZ77 copy in flight (S_STORED: raw bytes left in copy_len)
-  uint32_t pend_lo = 0, pend_hi = 0;     // its next (up to) 8 source bytes, requested a step ahead
+  ln.opos = 0;
+  ln.state = have ? S_BLOCK : S_DONE;
+  ln.err = 0;
+  ln.final_block = false;
+  ln.lit_min = ln.dist_min = ln.cl_min = 0;
+  ln.hdr_i = ln.hdr_n = ln.hdr_nlit = ln.hdr_ndist = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) ln.lit_lim.p[k] = ln.dist_lim.p[k] = us2{0, 0};
+  ln.match_len = ln.copy_len = ln.copy_dist = 0;
+  ln.pend_lo = ln.pend_hi = 0;
+  ln.lit_acc = ln.lit_n = 0;
 
-  // One step: (1) the state blocks -- ALU and LDS only in the hot states (S_SYM, S_DIST,
-  // S_DYN_LENS), they read the bit window but never touch global memory; (2) the stores, which
-  // consume the copy bytes requested at the end of the previous step, and the advance of the bit
-  // window into the dword requested then; (3) the loads for the next step.  The wavefront has one
-  // vmcnt counter for all lanes, so this order gives one memory wait per step, overlapped with
-  // (1).  A hot state takes at most 15+13 bits per step, so the 64-bit window never runs dry.
+  // One step: (1) decode -- ALU and LDS only, reads the bit window but never global memory;
+  // (2) the stores, which consume the copy bytes requested at the end of the previous step, and
+  // the advance of the bit window into the dword requested then; (3) the loads for the next
+  // step.  The wavefront has one vmcnt counter for all lanes, so this order gives one memory
+  // wait per step, overlapped with (1).  A step takes at most 63 bits minus the window offset
+  // (<= 31 at its start, every decode checks what is left), so the 64-bit window never runs dry
+  // and advances by at most one dword.
   // A lane decodes its next symbol in the same step that stores the last chunk of its copy.
   for (uint32_t guard = 0; guard < 0x20000000u; ++guard) {
-    if (__ballot(state != S_DONE || copy_len != 0) == 0) break;
+    if (__ballot(ln.state != S_DONE || ln.copy_len != 0) == 0) break;
+
+    if ((ln.state == S_BLOCK || ln.state == S_DYN_LENS) ? ln.copy_len == 0 : ln.state == S_STORED) {
+      Lane tmp = ln;
+      slow_step<LPW>(tmp, lds_lane);
+      ln = tmp;
+    }
 
     uint32_t k = 0;  // bytes of the copy in flight that go out this step
-    if (state != S_STORED && copy_len != 0) {
-      k = copy_len < copy_dist ? copy_len : copy_dist;  // source bytes that already exist
+    if (ln.state != S_STORED && ln.copy_len != 0) {
+      k = ln.copy_len < ln.copy_dist ? ln.copy_len : ln.copy_dist;  // source bytes that already exist
       if (k > 8u) k = 8u;
     }
-    const bool last_chunk = copy_len == k;
-    const uint32_t opos_eff = opos + k;
-    bool lit_store = false, new_match = false;
-    uint32_t lit_val = 0, new_dist = 0;
+    const bool last_chunk = ln.copy_len == k;
+    const uint32_t copy_dst = ln.opos;  // where phase (2) stores those k bytes
+    ln.opos += k;                       // from here on opos is the logical end of the output
+    const uint64_t win = ((uint64_t)b.w1 << 32) | b.w0;
+    bool new_match = false;
+    uint32_t new_dist = 0;
 
-    if (state == S_SYM && last_chunk) {  // read_literal (:565-630): literal/length symbol + extra
-      const int v = shuff_sym<true>(b, L, kOffLitSorted, kOffLitMeta, lit_min, lit_lim, &err);
-      if (v >= 0) {
-        if (v < 256) {
-          lit_store = opos_eff < out_cap;
-          lit_val = (uint32_t)v;
-          if (!lit_store) err = E_OUT_SMALL;
-        } else if (v == 256) {
-          state = S_BLOCK;  // finish_block
-        } else if (v > 285) {
-          err = E_CORRUPT;
+    // read_literal (inflate.mbt:565-630): literal/length symbols + length extra bits, up to
+    // kSymPerStep per step -- the memory round trip at the end of a step is the same for one
+    // symbol or three.  A lane goes on while it decodes literals, has room for them in lit_acc and
+    // the window still holds 15+5 bits.  The checks of huff_sym and more_bits are evaluated
+    // without branches, in the reference's order.
+    for (int r = 0; r < kSymPerStep; ++r) {
+      const bool go = ln.state == S_SYM && last_chunk && ln.lit_n < 4u && b.bitpos - b.widx * 32u <= 43u;
+      if (__ballot(go) == 0) break;
+      if (go) {
+        const uint32_t w = (uint32_t)(win >> (b.bitpos - b.widx * 32u));  // >= 20 valid bits
+        uint32_t sym;
+        const uint32_t len = canon_decode<true>(L, w, kOffLitSorted, kOffLitMeta, ln.lit_lim, &sym);
+        const bool nocode = len > 15u;
+        // :590-617 in closed form: 257..264 -> 3..10; 265..284 -> ((4|(x&3)) << n) + 3, x = sym-261
+        const uint32_t x = sym - 261u;
+        uint32_t n = sym >= 265u ? x >> 2 : 0u;
+        uint32_t base = sym >= 265u ? ((4u | (x & 3u)) << n) + 3u : sym - 254u;
+        if (sym >= 285u) {
+          n = 0;
+          base = 258;
+        }
+        if (sym <= 256u) n = 0;
+        const uint32_t t1 = b.bitpos + (uint32_t)ln.lit_min, t2 = b.bitpos + len, t3 = t2 + n;
+        int e = 0;
+        if (sym < 256u && ln.opos >= ln.out_cap) e = E_OUT_SMALL;
+        if (t3 > b.in_bits) e = E_EOF;
+        if (sym > 285u) e = E_CORRUPT;
+        if (t2 > b.in_bits) e = E_EOF;
+        if (nocode) e = E_CORRUPT;
+        if (t1 > b.in_bits) e = E_EOF;
+        const uint32_t asked = nocode ? t1 : (sym > 285u ? t2 : t3);
+        b.hi = b.hi > t1 ? b.hi : t1;
+        b.hi = b.hi > asked ? b.hi : asked;
+        if (e) {
+          ln.err = e;
+          ln.state = S_DONE;
         } else {
-          // :590-617 in closed form: 257..264 -> 3..10; 265..284 -> ((4|(x&3)) << n) + 3, x = v-261
-          uint32_t length = (uint32_t)v - 254u, n = 0;
-          if (v >= 265) {
-            n = ((uint32_t)v - 261u) >> 2;
-            length = ((4u | (((uint32_t)v - 261u) & 3u)) << n) + 3u;
+          b.bitpos = t3;
+          if (sym < 256u) {
+            ln.lit_acc |= sym << (8u * ln.lit_n);
+            ++ln.lit_n;
+            ++ln.opos;
           }
-          if (v == 285) {
-            length = 258;
-            n = 0;
-          }
-          const uint32_t w = sb_peek(b);
-          if (!sb_need(b, n)) {
-            err = E_EOF;
-          } else {
-            sb_take(b, n);
-            match_len = length + (w & ((1u << n) - 1u));
-            state = S_DIST;
-          }
-        }
-      }
-    } else if (state == S_DIST && last_chunk) {  // read_literal (:631-684): distance symbol + extra
-      const int d = shuff_sym<false>(b, L, kOffDistSorted, kOffDistMeta, dist_min, dist_lim, &err);
-      if (d >= 0) {
-        if (d >= kMaxDist) {
-          err = E_CORRUPT;
-        } else {
-          const uint32_t nb = d < 4 ? 0u : (uint32_t)(d - 2) >> 1;
-          const uint32_t w = sb_peek(b);
-          if (!sb_need(b, nb)) {
-            err = E_EOF;
-          } else {
-            sb_take(b, nb);
-            const uint32_t dist =
-                d < 4 ? (uint32_t)d + 1u : (1u << (nb + 1)) + 1u + (((uint32_t)d & 1u) << nb) + (w & ((1u << nb) - 1u));
-            const uint32_t hist = opos_eff < 32768u ? opos_eff : 32768u;  // hist_size
-            if (dist > hist) {
-              err = E_CORRUPT;
-            } else if (match_len > out_cap - opos_eff) {
-              err = E_OUT_SMALL;
-            } else {
-              new_match = true;
-              new_dist = dist;
-              state = S_SYM;
-            }
-          }
-        }
-      }
-    } else if (state == S_DYN_LENS && copy_len == 0) {  // :471-536, one code-length symbol per step
-      if (hdr_i >= hdr_n) {
-        bool ok = sdec_init<true>(L, 32, hdr_nlit, kOffLitSorted, kOffLitMeta, &lit_min, lit_lim);
-        ok = sdec_init<false>(L, 32 + hdr_nlit, hdr_ndist, kOffDistSorted, kOffDistMeta, &dist_min, dist_lim) && ok;
-        if (!ok) {
-          err = E_CORRUPT;
-        } else {
-          const int eob = (int)L.len_get(32 + 256);
-          if (lit_min < eob) lit_min = eob;  // :542-544
-          state = S_SYM;
-        }
-      } else {
-        const int x = shuff_sym<false>(b, L, kOffDistSorted, kOffDistMeta, cl_min, dist_lim, &err);
-        if (x >= 0) {
-          if (x < 16) {
-            L.len_set(32 + hdr_i, (uint32_t)x);
-            ++hdr_i;
-          } else {
-            int rep = x == 18 ? 11 : 3;
-            const uint32_t nb = x == 16 ? 2u : (x == 17 ? 3u : 7u);
-            uint32_t fill = 0;
-            if (x == 16 && hdr_i == 0) {
-              err = E_CORRUPT;
-            } else {
-              if (x == 16) fill = L.len_get(32 + hdr_i - 1);
-              const uint32_t w = sb_peek(b);
-              if (!sb_need(b, nb)) {
-                err = E_EOF;
-              } else {
-                sb_take(b, nb);
-                rep += (int)(w & ((1u << nb) - 1u));
-                if (hdr_i + rep > hdr_n) {
-                  err = E_CORRUPT;
-                } else {
-                  for (int j = 0; j < rep; ++j) L.len_set(32 + hdr_i + j, fill);
-                  hdr_i += rep;
-                }
-              }
-            }
-          }
-        }
-      }
-    } else if (state == S_BLOCK && copy_len == 0) {  // next_block (inflate.mbt:345-379)
-      sb_sync(b);
-      if (final_block) {
-        state = S_DONE;
-      } else if (!sb_need(b, 3)) {
-        err = E_EOF;
-      } else {
-        const uint32_t h = sb_peek(b) & 7u;
-        final_block = h & 1;
-        const uint32_t typ = h >> 1;
-        sb_take(b, 3);
-        if (typ == 3) {
-          err = E_CORRUPT;
-        } else if (typ == 0) {  // data_block (:708-737): header bytes follow the bytes read so far
-          const uint32_t p = sb_roffset(b);
-          if (b.in_len - p < 4) {
-            b.hi = b.in_bits;
-            err = E_EOF;
-          } else {
-            b.hi = (p + 4) * 8u;
-            const uint32_t n = (uint32_t)b.in[p] | ((uint32_t)b.in[p + 1] << 8);
-            const uint32_t nn = (uint32_t)b.in[p + 2] | ((uint32_t)b.in[p + 3] << 8);
-            if ((nn & 0xffffu) != ((~n) & 0xffffu)) {
-              err = E_CORRUPT;
-            } else {
-              copy_len = n;
-              state = S_STORED;
-            }
-          }
-        } else if (typ == 1) {  // fixed tables (:886-939); distances are 5-bit codes
-          for (int i = 0; i < 288; ++i) L.len_set(i, i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8)));
-          for (int i = 0; i < 32; ++i) L.len_set(288 + i, 5);
-          sdec_init<true>(L, 0, 288, kOffLitSorted, kOffLitMeta, &lit_min, lit_lim);
-          sdec_init<false>(L, 288, 32, kOffDistSorted, kOffDistMeta, &dist_min, dist_lim);
-          state = S_SYM;
-        } else {  // read_huffman (:429-470)
-          if (!sb_need(b, 14)) {
-            err = E_EOF;
-          } else {
-            const uint32_t v = sb_peek(b) & 0x3fffu;
-            hdr_nlit = (int)(v & 31u) + 257;
-            hdr_ndist = (int)((v >> 5) & 31u) + 1;
-            const int nclen = (int)((v >> 10) & 15u) + 4;
-            if (hdr_nlit > kMaxLit || hdr_ndist > kMaxDist) {
-              err = E_CORRUPT;
-            } else {
-              sb_take(b, 14);
-              sb_sync(b);
-              for (int i = 0; i < kNumCodes; ++i) L.len_set(i, 0);
-              for (int i = 0; i < nclen && !err; ++i) {
-                if (!sb_need(b, 3)) {
-                  err = E_EOF;
-                } else {
-                  L.len_set(kCodeOrder[i], sb_peek(b) & 7u);
-                  sb_take(b, 3);
-                  sb_sync(b);
-                }
-              }
-              if (!err) {
-                if (!sdec_init<false>(L, 0, kNumCodes, kOffDistSorted, kOffDistMeta, &cl_min, dist_lim)) {
-                  err = E_CORRUPT;
-                } else {
-                  hdr_i = 0;
-                  hdr_n = hdr_nlit + hdr_ndist;
-                  state = S_DYN_LENS;
-                }
-              }
-            }
-          }
-        }
-      }
-    } else if (state == S_STORED) {  // copy_data (:742-766): 8 raw bytes per step
-      if (copy_len == 0) {
-        sb_start(b, sb_roffset(b));  // restart the bit reader at the byte after the block
-        state = S_BLOCK;
-      } else {
-        const uint32_t p = sb_roffset(b);
-        const uint32_t avail = b.in_len - p;
-        uint32_t n = copy_len < 8u ? copy_len : 8u;
-        if (n > avail) n = avail;
-        if (n > out_cap - opos) {
-          err = E_OUT_SMALL;
-        } else if (n == 0) {
-          err = E_EOF;
-        } else {
-          for (uint32_t i = 0; i < n; ++i) out[opos + i] = b.in[p + i];
-          opos += n;
-          b.hi = (p + n) * 8u;
-          copy_len -= n;
+          ln.match_len = base + ((w >> len) & ((1u << n) - 1u));
+          ln.state = sym < 256u ? S_SYM : (sym == 256u ? S_BLOCK : S_DIST);  // 256: finish_block
         }
       }
     }
-    if (err) {
-      state = S_DONE;
-      if (k == 0) copy_len = 0;  // a raw-block count must not keep the lane alive
+    // read_literal (:631-684): distance symbol + extra -- in the step that decoded the length
+    // whenever the window still holds the 28 bits this may take (one dword crossing per step)
+    const uint32_t off2 = b.bitpos - b.widx * 32u;
+    if (ln.state == S_DIST && last_chunk && off2 <= 35u) {
+      const uint32_t w = (uint32_t)(win >> off2);  // >= 29 valid bits
+      uint32_t d;
+      const uint32_t len = canon_decode<false>(L, w, kOffDistSorted, kOffDistMeta, ln.dist_lim, &d);
+      const bool nocode = len > 15u;
+      const uint32_t nb = d < 4u ? 0u : (d - 2u) >> 1;
+      const uint32_t dist =
+          d < 4u ? d + 1u : (1u << (nb + 1u)) + 1u + ((d & 1u) << nb) + ((w >> len) & ((1u << nb) - 1u));
+      const uint32_t t1 = b.bitpos + (uint32_t)ln.dist_min, t2 = b.bitpos + len, t3 = t2 + nb;
+      const uint32_t hist = ln.opos < 32768u ? ln.opos : 32768u;  // hist_size
+      int e = 0;
+      if (ln.match_len > ln.out_cap - ln.opos) e = E_OUT_SMALL;
+      if (dist > hist) e = E_CORRUPT;
+      if (t3 > b.in_bits) e = E_EOF;
+      if (d >= (uint32_t)kMaxDist) e = E_CORRUPT;
+      if (t2 > b.in_bits) e = E_EOF;
+      if (nocode) e = E_CORRUPT;
+      if (t1 > b.in_bits) e = E_EOF;
+      const uint32_t asked = nocode ? t1 : (d >= (uint32_t)kMaxDist ? t2 : t3);
+      b.hi = b.hi > t1 ? b.hi : t1;
+      b.hi = b.hi > asked ? b.hi : asked;
+      if (e) {
+        ln.err = e;
+        ln.state = S_DONE;
+      } else {
+        b.bitpos = t3;
+        new_match = true;
+        new_dist = dist;
+        ln.state = S_SYM;
+      }
     }
 
     // (2) consume what the previous step requested (the only wait on global memory): advance the
-    // bit window, then the stores -- copy (copy_history :689 / write_copy), literal
+    // bit window, then the stores -- copy (copy_history :689 / write_copy), literals
     const bool crossed = (b.bitpos >> 5) != b.widx;
     if (crossed) {
       b.w0 = b.w1;
       b.w1 = b.nxt;
       ++b.widx;
     }
+    // Every lane-store is its own cache line, so stores are kept few and wide.  A store may
+    // write (inside the stream's slot) past the bytes that are final: the lane's next store starts
+    // right after the final ones and overwrites the rest, and nothing reads them before that.
     if (k != 0) {
-      uint8_t *dst = out + opos;
-      if (k == 8u) {
-        __builtin_memcpy(dst, &pend_lo, 4);
-        __builtin_memcpy(dst + 4, &pend_hi, 4);
+      uint8_t *dst = ln.out + copy_dst;
+      if (copy_dst + 8u <= ln.out_cap) {
+        const uint64_t v = ((uint64_t)ln.pend_hi << 32) | ln.pend_lo;
+        __builtin_memcpy(dst, &v, 8);
       } else {
-        uint32_t v = pend_lo;
+        uint32_t v = ln.pend_lo;
         if (k & 4u) {
           __builtin_memcpy(dst, &v, 4);
           dst += 4;
-          v = pend_hi;
+          v = ln.pend_hi;
         }
         if (k & 2u) {
           const uint16_t h = (uint16_t)v;
@@ -1005,43 +1106,52 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
           dst += 2;
           v >>= 16;
         }
-        if (k & 1u) *dst = (uint8_t)v;
+        if (k & 1u) *dst = (uint8_t)v;  // (k == 8 always has room: the copy was checked to fit)
       }
-      opos += k;
-      copy_len -= k;
+      ln.copy_len -= k;
     }
-    if (lit_store) out[opos++] = (uint8_t)lit_val;
+    // literals collect in a register: one dword store per four, or when something else follows
+    if (ln.lit_n != 0 && (ln.lit_n == 4u || ln.state != S_SYM || new_match)) {
+      uint8_t *dst = ln.out + ln.opos - ln.lit_n;
+      if (ln.opos - ln.lit_n + 4u <= ln.out_cap) {
+        __builtin_memcpy(dst, &ln.lit_acc, 4);
+      } else {
+        for (uint32_t i = 0; i < ln.lit_n; ++i) dst[i] = (uint8_t)(ln.lit_acc >> (8u * i));
+      }
+      ln.lit_n = 0;
+      ln.lit_acc = 0;
+    }
     if (new_match) {
-      copy_len = match_len;
-      copy_dist = new_dist;
+      ln.copy_len = ln.match_len;
+      ln.copy_dist = new_dist;
     }
     // (3) loads for the next step
     if (crossed) b.nxt = sb_load(b, b.widx + 2);
-#ifndef FLATE_EXP_NO_HISTORY_READ
-    if (state != S_STORED && copy_len != 0) {
-      const uint8_t *src = out + opos - copy_dist;
-      if (opos - copy_dist + 8u <= out_cap) {  // the 8-byte read stays inside this stream's slot
-        pend_lo = ld32g(src);
-        pend_hi = ld32g(src + 4);
+    if (ln.state != S_STORED && ln.copy_len != 0) {
+      const uint8_t *src = ln.out + ln.opos - ln.copy_dist;
+      if (ln.opos - ln.copy_dist + 8u <= ln.out_cap) {  // the 8-byte read stays inside this stream's slot
+        ln.pend_lo = ld32g(src);
+        ln.pend_hi = ld32g(src + 4);
       } else {
-        uint32_t n = copy_len < copy_dist ? copy_len : copy_dist;
+        uint32_t n = ln.copy_len < ln.copy_dist ? ln.copy_len : ln.copy_dist;
         if (n > 8u) n = 8u;
         uint64_t v = 0;
         for (uint32_t i = 0; i < n; ++i) v |= (uint64_t)src[i] << (8 * i);
-        pend_lo = (uint32_t)v;
-        pend_hi = (uint32_t)(v >> 32);
+        ln.pend_lo = (uint32_t)v;
+        ln.pend_hi = (uint32_t)(v >> 32);
       }
     }
-#endif
   }
   if (have) {
-    P.out_len[sid] = opos;
-    P.status[sid] = err;
-    P.err_off[sid] = err == E_CORRUPT ? (long long)sb_roffset(b) : -1;
+    P.out_len[sid] = ln.opos;
+    P.status[sid] = ln.err;
+    P.err_off[sid] = ln.err == E_CORRUPT ? (long long)sb_roffset(b) : -1;
   }
 }
 template __global__ void inflate_simt_kernel<64>(InfParams);
 template __global__ void inflate_simt_kernel<32>(InfParams);
 template __global__ void inflate_simt_kernel<16>(InfParams);
+
+size_t inflate_simt_lds_bytes(int lanes_per_wave) { return (size_t)kLaneWords * lanes_per_wave * sizeof(uint16_t); }
 
 }  // namespace flate
