@@ -563,7 +563,7 @@ constexpr int kOffLens = kOffDistMeta + 16;           // 352 code lengths (32 + 
 constexpr int kLaneWords = kOffLens + 88;             // 296
 
 enum SState { S_BLOCK = 0, S_DYN_LENS, S_SYM, S_DIST, S_STORED, S_DONE };
-constexpr int kSymPerStep = 3;  // literal/length symbols one lane may decode per step
+constexpr int kSymPerStep = 4;  // literal/length symbols one lane may decode per step
 
 // The 15 code-length limits of one Huffman code, two per register (see shuff_sym).
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
@@ -589,15 +589,16 @@ struct LaneLds {
   }
 };
 
-// Bit reader of one lane: the consumed-bit position plus the two dwords under it; `nxt` is the
-// dword after those, always requested one step ahead.  The reference reads its input byte-wise
+// Bit reader of one lane: the consumed-bit position plus the three dwords under it; the two
+// dwords after those are always requested one step ahead.  The reference reads its input byte-wise
 // (inflate.mbt:771 more_bits); its roffset -- reported by corrupt_input_error -- equals
 // ceil(hi / 8), hi = the highest bit position any read has asked for.
 struct SBits {
   const uint8_t *in;
   uint32_t in_len, in_bits;
   uint32_t bitpos, hi;
-  uint32_t w0, w1, nxt, widx;  // w0 = dword widx of the stream, w1 = widx+1, nxt = widx+2
+  uint32_t w0, w1, w2, widx;  // the window: dwords widx, widx+1, widx+2 of the stream
+  uint32_t n0, n1;            // dwords widx+3, widx+4, requested one step ahead
 };
 
 FLATE_D uint32_t sb_load(const SBits &b, uint32_t widx) {
@@ -610,6 +611,22 @@ FLATE_D uint32_t sb_load(const SBits &b, uint32_t widx) {
   }
   return w;
 }
+// dwords widx and widx+1 in one request
+FLATE_D uint64_t sb_load2(const SBits &b, uint32_t widx) {
+  const uint32_t pos = widx * 4u;
+  uint64_t v;
+  if (pos + 8 <= b.in_len) {
+    __builtin_memcpy(&v, b.in + pos, 8);
+  } else {
+    v = sb_load(b, widx) | ((uint64_t)sb_load(b, widx + 1) << 32);
+  }
+  // Hide that the halves come from one register pair: otherwise the two field stores are merged
+  // into one 8-byte store, and that keeps the whole lane state in scratch memory instead of
+  // registers (scalar replacement gives up on the mixed-width accesses).
+  uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+  asm volatile("" : "+v"(lo), "+v"(hi));
+  return ((uint64_t)hi << 32) | lo;
+}
 // s_waitcnt vmcnt(0) (gfx9 encoding: vmcnt 0, expcnt/lgkmcnt untouched).  The block-header paths
 // load straight into the window registers; waiting there keeps the compiler from guarding every
 // use of the window in the hot states with a wait that would also cover the prefetches.
@@ -618,15 +635,27 @@ FLATE_D void vm_wait_all() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 FLATE_D void sb_start(SBits &b, uint32_t byte_pos) {
   b.bitpos = b.hi = byte_pos * 8u;
   b.widx = byte_pos >> 2;
-  b.w0 = sb_load(b, b.widx);
-  b.w1 = sb_load(b, b.widx + 1);
-  b.nxt = sb_load(b, b.widx + 2);
+  // (pairs as the struct lays them out: a merged 8-byte store across two pairs would keep the
+  // whole lane state from being promoted to registers)
+  const uint64_t a = sb_load2(b, b.widx), c = sb_load2(b, b.widx + 3);
+  b.w0 = (uint32_t)a;
+  b.w1 = (uint32_t)(a >> 32);
+  b.w2 = sb_load(b, b.widx + 2);
+  b.n0 = (uint32_t)c;
+  b.n1 = (uint32_t)(c >> 32);
   vm_wait_all();
 }
-// the next 32 bits; valid while bitpos is inside w0/w1, i.e. after <= 32 bits taken since a sync
-FLATE_D uint32_t sb_peek(const SBits &b) {
-  return (uint32_t)((((uint64_t)b.w1 << 32) | b.w0) >> (b.bitpos - b.widx * 32u));
+// The next 32 bits at window offset off = bitpos - 32*widx (0..95); past offset 64 only the
+// first 96 - off of them are real, the callers check what they use.
+FLATE_D uint32_t sb_window(const SBits &b, uint32_t off) {
+  // (selects over values, not over the fields themselves: a load from a selected field address
+  // is dynamic indexing, and that would keep the bit reader in scratch memory)
+  const uint32_t w0 = b.w0, w1 = b.w1, w2 = b.w2;
+  const uint32_t lo = off < 32u ? w0 : (off < 64u ? w1 : w2);
+  const uint32_t hi = off < 32u ? w1 : (off < 64u ? w2 : 0u);
+  return (uint32_t)((((uint64_t)hi << 32) | lo) >> (off & 31u));
 }
+FLATE_D uint32_t sb_peek(const SBits &b) { return sb_window(b, b.bitpos - b.widx * 32u); }
 FLATE_D bool sb_need(SBits &b, uint32_t n) {
   const uint32_t t = b.bitpos + n;
   b.hi = b.hi > t ? b.hi : t;
@@ -637,9 +666,11 @@ FLATE_D void sb_take(SBits &b, uint32_t n) { b.bitpos += n; }
 FLATE_D void sb_sync(SBits &b) {
   while ((b.bitpos >> 5) != b.widx) {
     b.w0 = b.w1;
-    b.w1 = b.nxt;
+    b.w1 = b.w2;
+    b.w2 = b.n0;
+    b.n0 = b.n1;
     ++b.widx;
-    b.nxt = sb_load(b, b.widx + 2);
+    b.n1 = sb_load(b, b.widx + 4);
     vm_wait_all();
   }
 }
@@ -651,9 +682,16 @@ FLATE_D uint32_t sb_roffset(const SBits &b) { return (b.hi + 7u) >> 3; }
 // to 15 bits; meta[k] = offs[k] - first[k] (mod 2^16), so sorted index = code + meta[k]; with THR,
 // meta[16+k] = first code of length k whose symbol is >= 256 (the sorted list keeps only the low
 // byte; inside one length symbols ascend, so those come last).
+// (results by value: handing out addresses of the caller's lane state would pin it in memory)
+struct DecInit {
+  Limits lim;
+  int mn;
+  bool ok;
+};
 template <bool THR, class LL>
-FLATE_D bool sdec_init(const LL &L, int lens_at, int n, int sorted_off, int meta_off, int *mn_out,
-                       Limits &lim_out) {
+FLATE_D DecInit sdec_init(const LL &L, int lens_at, int n, int sorted_off, int meta_off) {
+  DecInit R;
+  R.ok = true;
   uint32_t lim[16];
   uint32_t cnt[16], low[16];
 #pragma unroll
@@ -672,10 +710,10 @@ FLATE_D bool sdec_init(const LL &L, int lens_at, int n, int sorted_off, int meta
     if (cnt[k]) mn = k;
     if (cnt[k] && !mx) mx = k;
   }
-  *mn_out = mn;
+  R.mn = mn;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) lim_out.p[k] = us2{0, 0};
-  if (mx == 0) return true;  // empty tree (:143-145): every lookup is corrupt
+  for (int k = 0; k < 8; ++k) R.lim.p[k] = us2{0, 0};
+  if (mx == 0) return R;  // empty tree (:143-145): every lookup is corrupt
   lim[15] = 0;  // pad: never above the code bits
   uint32_t next_off[16];
   uint32_t code = 0, off = 0;
@@ -694,10 +732,13 @@ FLATE_D bool sdec_init(const LL &L, int lens_at, int n, int sorted_off, int meta
 #pragma unroll
     for (int k = 1; k < 16; ++k)
       if (k >= mn && k <= mx) cc = (cc << 1) + cnt[k];
-    if (cc != (1u << mx) && !(cc == 1 && mx == 1)) return false;
+    if (cc != (1u << mx) && !(cc == 1 && mx == 1)) {
+      R.ok = false;
+      return R;
+    }
   }
 #pragma unroll
-  for (int k = 0; k < 8; ++k) lim_out.p[k] = us2{(unsigned short)lim[2 * k], (unsigned short)lim[2 * k + 1]};
+  for (int k = 0; k < 8; ++k) R.lim.p[k] = us2{(unsigned short)lim[2 * k], (unsigned short)lim[2 * k + 1]};
   for (int i = 0; i < n; ++i) {
     const uint32_t l = L.len_get(lens_at + i);
     if (!l) continue;
@@ -707,7 +748,7 @@ FLATE_D bool sdec_init(const LL &L, int lens_at, int n, int sorted_off, int meta
       if (l == (uint32_t)k) at = next_off[k]++;
     L.set8(sorted_off, at, (uint32_t)i & 0xffu);
   }
-  return true;
+  return R;
 }
 
 // Canonical decode of one code, no loop and no branch: returns the code length (16 = no such
@@ -754,175 +795,8 @@ FLATE_D int shuff_sym(SBits &b, const LL &L, int sorted_off, int meta_off, int d
   return (int)sym;
 }
 
-// Everything one lane carries between steps.
-struct Lane {
-  SBits b;
-  uint8_t *out;
-  uint32_t out_cap, opos;
-  int state, err;
-  bool final_block;
-  int lit_min, dist_min, cl_min;
-  int hdr_i, hdr_n, hdr_nlit, hdr_ndist;
-  Limits lit_lim, dist_lim;        // dist_lim also serves the code-length code
-  uint32_t match_len;              // S_DIST: the length decoded by S_SYM
-  uint32_t copy_len, copy_dist;    // LZ77 copy in flight (S_STORED: raw bytes left, in copy_len)
-  uint32_t pend_lo, pend_hi;       // its next (up to) 8 source bytes, requested a step ahead
-  uint32_t lit_acc, lit_n;         // literals decoded but not stored yet (they end at opos)
-};
 
 extern __shared__ uint16_t simt_lds[];  // kLaneWords * LPW entries
-
-// One step of a lane in S_BLOCK, S_DYN_LENS or S_STORED: block headers, table construction, raw
-// blocks.  Out of line: these are a few hundred steps per block against tens of thousands of
-// symbol steps, and keeping them out of the step loop keeps that loop small.  Loads here block.
-template <int LPW>
-__attribute__((noinline)) FLATE_D void slow_step(Lane &ln, int lane) {
-  const LaneLds<LPW> L = {simt_lds + lane};
-  SBits &b = ln.b;
-  int err = 0;
-  if (ln.state == S_DYN_LENS) {  // inflate.mbt:471-536, one code-length symbol per step
-    if (ln.hdr_i >= ln.hdr_n) {
-      // (the code-length decoder sits in the distance slots: the literal code is built first)
-      bool ok = sdec_init<true>(L, 32, ln.hdr_nlit, kOffLitSorted, kOffLitMeta, &ln.lit_min, ln.lit_lim);
-      ok = sdec_init<false>(L, 32 + ln.hdr_nlit, ln.hdr_ndist, kOffDistSorted, kOffDistMeta, &ln.dist_min,
-                            ln.dist_lim) && ok;
-      if (!ok) {
-        err = E_CORRUPT;
-      } else {
-        const int eob = (int)L.len_get(32 + 256);
-        if (ln.lit_min < eob) ln.lit_min = eob;  // :542-544
-        ln.state = S_SYM;
-      }
-    } else {
-      sb_sync(b);
-      const int x = shuff_sym(b, L, kOffDistSorted, kOffDistMeta, ln.cl_min, ln.dist_lim, &err);
-      if (x >= 0) {
-        if (x < 16) {
-          L.len_set(32 + ln.hdr_i, (uint32_t)x);
-          ++ln.hdr_i;
-        } else {
-          int rep = x == 18 ? 11 : 3;
-          const uint32_t nb = x == 16 ? 2u : (x == 17 ? 3u : 7u);
-          uint32_t fill = 0;
-          if (x == 16 && ln.hdr_i == 0) {
-            err = E_CORRUPT;
-          } else {
-            if (x == 16) fill = L.len_get(32 + ln.hdr_i - 1);
-            const uint32_t w = sb_peek(b);
-            if (!sb_need(b, nb)) {
-              err = E_EOF;
-            } else {
-              sb_take(b, nb);
-              rep += (int)(w & ((1u << nb) - 1u));
-              if (ln.hdr_i + rep > ln.hdr_n) {
-                err = E_CORRUPT;
-              } else {
-                for (int j = 0; j < rep; ++j) L.len_set(32 + ln.hdr_i + j, fill);
-                ln.hdr_i += rep;
-              }
-            }
-          }
-        }
-      }
-    }
-  } else if (ln.state == S_BLOCK) {  // next_block (inflate.mbt:345-379)
-    sb_sync(b);
-    if (ln.final_block) {
-      ln.state = S_DONE;
-    } else if (!sb_need(b, 3)) {
-      err = E_EOF;
-    } else {
-      const uint32_t h = sb_peek(b) & 7u;
-      ln.final_block = h & 1;
-      const uint32_t typ = h >> 1;
-      sb_take(b, 3);
-      if (typ == 3) {
-        err = E_CORRUPT;
-      } else if (typ == 0) {  // data_block (:708-737): header bytes follow the bytes read so far
-        const uint32_t p = sb_roffset(b);
-        if (b.in_len - p < 4) {
-          b.hi = b.in_bits;
-          err = E_EOF;
-        } else {
-          b.hi = (p + 4) * 8u;
-          const uint32_t n = (uint32_t)b.in[p] | ((uint32_t)b.in[p + 1] << 8);
-          const uint32_t nn = (uint32_t)b.in[p + 2] | ((uint32_t)b.in[p + 3] << 8);
-          if ((nn & 0xffffu) != ((~n) & 0xffffu)) {
-            err = E_CORRUPT;
-          } else {
-            ln.copy_len = n;
-            ln.state = S_STORED;
-          }
-        }
-      } else if (typ == 1) {  // fixed tables (:886-939); distances are 5-bit codes
-        for (int i = 0; i < 288; ++i) L.len_set(i, i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8)));
-        for (int i = 0; i < 32; ++i) L.len_set(288 + i, 5);
-        sdec_init<true>(L, 0, 288, kOffLitSorted, kOffLitMeta, &ln.lit_min, ln.lit_lim);
-        sdec_init<false>(L, 288, 32, kOffDistSorted, kOffDistMeta, &ln.dist_min, ln.dist_lim);
-        ln.state = S_SYM;
-      } else if (!sb_need(b, 14)) {  // read_huffman (:429-470)
-        err = E_EOF;
-      } else {
-        const uint32_t v = sb_peek(b) & 0x3fffu;
-        ln.hdr_nlit = (int)(v & 31u) + 257;
-        ln.hdr_ndist = (int)((v >> 5) & 31u) + 1;
-        const int nclen = (int)((v >> 10) & 15u) + 4;
-        if (ln.hdr_nlit > kMaxLit || ln.hdr_ndist > kMaxDist) {
-          err = E_CORRUPT;
-        } else {
-          sb_take(b, 14);
-          sb_sync(b);
-          for (int i = 0; i < kNumCodes; ++i) L.len_set(i, 0);
-          for (int i = 0; i < nclen && !err; ++i) {
-            if (!sb_need(b, 3)) {
-              err = E_EOF;
-            } else {
-              L.len_set(kCodeOrder[i], sb_peek(b) & 7u);
-              sb_take(b, 3);
-              sb_sync(b);
-            }
-          }
-          if (!err) {
-            if (!sdec_init<false>(L, 0, kNumCodes, kOffDistSorted, kOffDistMeta, &ln.cl_min, ln.dist_lim)) {
-              err = E_CORRUPT;
-            } else {
-              ln.hdr_i = 0;
-              ln.hdr_n = ln.hdr_nlit + ln.hdr_ndist;
-              ln.state = S_DYN_LENS;
-            }
-          }
-        }
-      }
-    }
-    sb_sync(b);
-  } else if (ln.state == S_STORED) {  // copy_data (:742-766): 8 raw bytes per step
-    if (ln.copy_len == 0) {
-      sb_start(b, sb_roffset(b));  // restart the bit reader at the byte after the block
-      ln.state = S_BLOCK;
-    } else {
-      const uint32_t p = sb_roffset(b);
-      const uint32_t avail = b.in_len - p;
-      uint32_t n = ln.copy_len < 8u ? ln.copy_len : 8u;
-      if (n > avail) n = avail;
-      if (n > ln.out_cap - ln.opos) {
-        err = E_OUT_SMALL;
-      } else if (n == 0) {
-        err = E_EOF;
-      } else {
-        for (uint32_t i = 0; i < n; ++i) ln.out[ln.opos + i] = b.in[p + i];
-        ln.opos += n;
-        b.hi = (p + n) * 8u;
-        ln.copy_len -= n;
-      }
-    }
-  }
-  if (err) {
-    ln.err = err;
-    ln.state = S_DONE;
-    ln.copy_len = 0;  // a raw-block count must not keep the lane alive
-  }
-  vm_wait_all();
-}
 
 }  // namespace
 
@@ -936,61 +810,227 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
   const bool have = lane < LPW && sid < P.n_streams;
   const LaneLds<LPW> L = {simt_lds + lds_lane};
 
-  Lane ln;
-  SBits &b = ln.b;
-  ln.out = P.out;
-  ln.out_cap = 0;
+  // the lane's state (plain locals: they must live in registers)
+  SBits b;
+  uint8_t *out;
+  uint32_t out_cap, opos;
+  int state, err;
+  bool final_block;
+  int lit_min, dist_min, cl_min;
+  int hdr_i, hdr_n, hdr_nlit, hdr_ndist;
+  Limits lit_lim, dist_lim;       // dist_lim also serves the code-length code
+  uint32_t match_len;             // S_DIST: the length decoded by S_SYM
+  uint32_t copy_len, copy_dist;   // LZ77 copy in flight (S_STORED: raw bytes left, in copy_len)
+  uint32_t pend_lo, pend_hi;      // its next (up to) 8 source bytes, requested a step ahead
+  uint32_t lit_lo, lit_hi, lit_n; // up to eight literals decoded but not stored yet (they end at opos)
+  out = P.out;
+  out_cap = 0;
   b.in = P.in;
   b.in_len = 0;
   if (have) {
-    ln.out = P.out + P.out_off[sid];
+    out = P.out + P.out_off[sid];
     const uint64_t cap64 = P.out_off[sid + 1] - P.out_off[sid];
-    ln.out_cap = cap64 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)cap64;
+    out_cap = cap64 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)cap64;
     b.in = P.in + P.in_off[sid];
     b.in_len = (uint32_t)(P.in_off[sid + 1] - P.in_off[sid]);  // < 2^28: checked by the host
   }
   b.in_bits = b.in_len * 8u;
   b.bitpos = b.hi = b.widx = 0;
-  b.w0 = b.w1 = b.nxt = 0;
+  b.w0 = b.w1 = b.w2 = b.n0 = b.n1 = 0;
   if (have) sb_start(b, 0);
-  ln.opos = 0;
-  ln.state = have ? S_BLOCK : S_DONE;
-  ln.err = 0;
-  ln.final_block = false;
-  ln.lit_min = ln.dist_min = ln.cl_min = 0;
-  ln.hdr_i = ln.hdr_n = ln.hdr_nlit = ln.hdr_ndist = 0;
+  opos = 0;
+  state = have ? S_BLOCK : S_DONE;
+  err = 0;
+  final_block = false;
+  lit_min = dist_min = cl_min = 0;
+  hdr_i = hdr_n = hdr_nlit = hdr_ndist = 0;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) ln.lit_lim.p[k] = ln.dist_lim.p[k] = us2{0, 0};
-  ln.match_len = ln.copy_len = ln.copy_dist = 0;
-  ln.pend_lo = ln.pend_hi = 0;
-  ln.lit_acc = ln.lit_n = 0;
+  for (int k = 0; k < 8; ++k) lit_lim.p[k] = dist_lim.p[k] = us2{0, 0};
+  match_len = copy_len = copy_dist = 0;
+  pend_lo = pend_hi = 0;
+  lit_lo = lit_hi = lit_n = 0;
+
+  // One step of a lane in S_BLOCK, S_DYN_LENS or S_STORED: block headers, table construction, raw
+  // blocks -- a few hundred steps per block against thousands of symbol steps.  Loads here block.
+  auto slow_step = [&]() {
+    int serr = 0;
+    if (state == S_DYN_LENS) {  // inflate.mbt:471-536, one code-length symbol per step
+      if (hdr_i >= hdr_n) {
+        // (the code-length decoder sits in the distance slots: the literal code is built first)
+        const DecInit lit = sdec_init<true>(L, 32, hdr_nlit, kOffLitSorted, kOffLitMeta);
+        const DecInit dst = sdec_init<false>(L, 32 + hdr_nlit, hdr_ndist, kOffDistSorted, kOffDistMeta);
+        lit_lim = lit.lim;
+        lit_min = lit.mn;
+        dist_lim = dst.lim;
+        dist_min = dst.mn;
+        if (!lit.ok || !dst.ok) {
+          serr = E_CORRUPT;
+        } else {
+          const int eob = (int)L.len_get(32 + 256);
+          if (lit_min < eob) lit_min = eob;  // :542-544
+          state = S_SYM;
+        }
+      } else {
+        sb_sync(b);
+        const int x = shuff_sym(b, L, kOffDistSorted, kOffDistMeta, cl_min, dist_lim, &serr);
+        if (x >= 0) {
+          if (x < 16) {
+            L.len_set(32 + hdr_i, (uint32_t)x);
+            ++hdr_i;
+          } else {
+            int rep = x == 18 ? 11 : 3;
+            const uint32_t nb = x == 16 ? 2u : (x == 17 ? 3u : 7u);
+            uint32_t fill = 0;
+            if (x == 16 && hdr_i == 0) {
+              serr = E_CORRUPT;
+            } else {
+              if (x == 16) fill = L.len_get(32 + hdr_i - 1);
+              const uint32_t w = sb_peek(b);
+              if (!sb_need(b, nb)) {
+                serr = E_EOF;
+              } else {
+                sb_take(b, nb);
+                rep += (int)(w & ((1u << nb) - 1u));
+                if (hdr_i + rep > hdr_n) {
+                  serr = E_CORRUPT;
+                } else {
+                  for (int j = 0; j < rep; ++j) L.len_set(32 + hdr_i + j, fill);
+                  hdr_i += rep;
+                }
+              }
+            }
+          }
+        }
+      }
+    } else if (state == S_BLOCK) {  // next_block (inflate.mbt:345-379)
+      sb_sync(b);
+      if (final_block) {
+        state = S_DONE;
+      } else if (!sb_need(b, 3)) {
+        serr = E_EOF;
+      } else {
+        const uint32_t h = sb_peek(b) & 7u;
+        final_block = h & 1;
+        const uint32_t typ = h >> 1;
+        sb_take(b, 3);
+        if (typ == 3) {
+          serr = E_CORRUPT;
+        } else if (typ == 0) {  // data_block (:708-737): header bytes follow the bytes read so far
+          const uint32_t p = sb_roffset(b);
+          if (b.in_len - p < 4) {
+            b.hi = b.in_bits;
+            serr = E_EOF;
+          } else {
+            b.hi = (p + 4) * 8u;
+            const uint32_t n = (uint32_t)b.in[p] | ((uint32_t)b.in[p + 1] << 8);
+            const uint32_t nn = (uint32_t)b.in[p + 2] | ((uint32_t)b.in[p + 3] << 8);
+            if ((nn & 0xffffu) != ((~n) & 0xffffu)) {
+              serr = E_CORRUPT;
+            } else {
+              copy_len = n;
+              state = S_STORED;
+            }
+          }
+        } else if (typ == 1) {  // fixed tables (:886-939); distances are 5-bit codes
+          for (int i = 0; i < 288; ++i) L.len_set(i, i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8)));
+          for (int i = 0; i < 32; ++i) L.len_set(288 + i, 5);
+          const DecInit lit = sdec_init<true>(L, 0, 288, kOffLitSorted, kOffLitMeta);
+          const DecInit dst = sdec_init<false>(L, 288, 32, kOffDistSorted, kOffDistMeta);
+          lit_lim = lit.lim;
+          lit_min = lit.mn;
+          dist_lim = dst.lim;
+          dist_min = dst.mn;
+          state = S_SYM;
+        } else if (!sb_need(b, 14)) {  // read_huffman (:429-470)
+          serr = E_EOF;
+        } else {
+          const uint32_t v = sb_peek(b) & 0x3fffu;
+          hdr_nlit = (int)(v & 31u) + 257;
+          hdr_ndist = (int)((v >> 5) & 31u) + 1;
+          const int nclen = (int)((v >> 10) & 15u) + 4;
+          if (hdr_nlit > kMaxLit || hdr_ndist > kMaxDist) {
+            serr = E_CORRUPT;
+          } else {
+            sb_take(b, 14);
+            sb_sync(b);
+            for (int i = 0; i < kNumCodes; ++i) L.len_set(i, 0);
+            for (int i = 0; i < nclen && !serr; ++i) {
+              if (!sb_need(b, 3)) {
+                serr = E_EOF;
+              } else {
+                L.len_set(kCodeOrder[i], sb_peek(b) & 7u);
+                sb_take(b, 3);
+                sb_sync(b);
+              }
+            }
+            if (!serr) {
+              const DecInit cl = sdec_init<false>(L, 0, kNumCodes, kOffDistSorted, kOffDistMeta);
+              dist_lim = cl.lim;
+              cl_min = cl.mn;
+              if (!cl.ok) {
+                serr = E_CORRUPT;
+              } else {
+                hdr_i = 0;
+                hdr_n = hdr_nlit + hdr_ndist;
+                state = S_DYN_LENS;
+              }
+            }
+          }
+        }
+      }
+      sb_sync(b);
+    } else if (state == S_STORED) {  // copy_data (:742-766): 8 raw bytes per step
+      if (copy_len == 0) {
+        sb_start(b, sb_roffset(b));  // restart the bit reader at the byte after the block
+        state = S_BLOCK;
+      } else {
+        const uint32_t p = sb_roffset(b);
+        const uint32_t avail = b.in_len - p;
+        uint32_t n = copy_len < 8u ? copy_len : 8u;
+        if (n > avail) n = avail;
+        if (n > out_cap - opos) {
+          serr = E_OUT_SMALL;
+        } else if (n == 0) {
+          serr = E_EOF;
+        } else {
+          for (uint32_t i = 0; i < n; ++i) out[opos + i] = b.in[p + i];
+          opos += n;
+          b.hi = (p + n) * 8u;
+          copy_len -= n;
+        }
+      }
+    }
+    if (serr) {
+      err = serr;
+      state = S_DONE;
+      copy_len = 0;  // a raw-block count must not keep the lane alive
+    }
+    vm_wait_all();
+  };
 
   // One step: (1) decode -- ALU and LDS only, reads the bit window but never global memory;
   // (2) the stores, which consume the copy bytes requested at the end of the previous step, and
   // the advance of the bit window into the dword requested then; (3) the loads for the next
   // step.  The wavefront has one vmcnt counter for all lanes, so this order gives one memory
-  // wait per step, overlapped with (1).  A step takes at most 63 bits minus the window offset
-  // (<= 31 at its start, every decode checks what is left), so the 64-bit window never runs dry
-  // and advances by at most one dword.
+  // wait per step, overlapped with (1).  A step takes at most 95 bits minus the window offset
+  // (<= 31 at its start, every decode checks what is left), so the 96-bit window never runs dry
+  // and advances by at most two dwords.
   // A lane decodes its next symbol in the same step that stores the last chunk of its copy.
   for (uint32_t guard = 0; guard < 0x20000000u; ++guard) {
-    if (__ballot(ln.state != S_DONE || ln.copy_len != 0) == 0) break;
+    if (__ballot(state != S_DONE || copy_len != 0) == 0) break;
 
-    if ((ln.state == S_BLOCK || ln.state == S_DYN_LENS) ? ln.copy_len == 0 : ln.state == S_STORED) {
-      Lane tmp = ln;
-      slow_step<LPW>(tmp, lds_lane);
-      ln = tmp;
+    if ((state == S_BLOCK || state == S_DYN_LENS) ? copy_len == 0 : state == S_STORED) {
+      slow_step();
     }
 
     uint32_t k = 0;  // bytes of the copy in flight that go out this step
-    if (ln.state != S_STORED && ln.copy_len != 0) {
-      k = ln.copy_len < ln.copy_dist ? ln.copy_len : ln.copy_dist;  // source bytes that already exist
+    if (state != S_STORED && copy_len != 0) {
+      k = copy_len < copy_dist ? copy_len : copy_dist;  // source bytes that already exist
       if (k > 8u) k = 8u;
     }
-    const bool last_chunk = ln.copy_len == k;
-    const uint32_t copy_dst = ln.opos;  // where phase (2) stores those k bytes
-    ln.opos += k;                       // from here on opos is the logical end of the output
-    const uint64_t win = ((uint64_t)b.w1 << 32) | b.w0;
+    const bool last_chunk = copy_len == k;
+    const uint32_t copy_dst = opos;  // where phase (2) stores those k bytes
+    opos += k;                       // from here on opos is the logical end of the output
     bool new_match = false;
     uint32_t new_dist = 0;
 
@@ -1000,12 +1040,12 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
     // the window still holds 15+5 bits.  The checks of huff_sym and more_bits are evaluated
     // without branches, in the reference's order.
     for (int r = 0; r < kSymPerStep; ++r) {
-      const bool go = ln.state == S_SYM && last_chunk && ln.lit_n < 4u && b.bitpos - b.widx * 32u <= 43u;
+      const bool go = state == S_SYM && last_chunk && lit_n < 8u && b.bitpos - b.widx * 32u <= 75u;
       if (__ballot(go) == 0) break;
       if (go) {
-        const uint32_t w = (uint32_t)(win >> (b.bitpos - b.widx * 32u));  // >= 20 valid bits
+        const uint32_t w = sb_peek(b);  // >= 21 real bits
         uint32_t sym;
-        const uint32_t len = canon_decode<true>(L, w, kOffLitSorted, kOffLitMeta, ln.lit_lim, &sym);
+        const uint32_t len = canon_decode<true>(L, w, kOffLitSorted, kOffLitMeta, lit_lim, &sym);
         const bool nocode = len > 15u;
         // :590-617 in closed form: 257..264 -> 3..10; 265..284 -> ((4|(x&3)) << n) + 3, x = sym-261
         const uint32_t x = sym - 261u;
@@ -1016,9 +1056,9 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
           base = 258;
         }
         if (sym <= 256u) n = 0;
-        const uint32_t t1 = b.bitpos + (uint32_t)ln.lit_min, t2 = b.bitpos + len, t3 = t2 + n;
+        const uint32_t t1 = b.bitpos + (uint32_t)lit_min, t2 = b.bitpos + len, t3 = t2 + n;
         int e = 0;
-        if (sym < 256u && ln.opos >= ln.out_cap) e = E_OUT_SMALL;
+        if (sym < 256u && opos >= out_cap) e = E_OUT_SMALL;
         if (t3 > b.in_bits) e = E_EOF;
         if (sym > 285u) e = E_CORRUPT;
         if (t2 > b.in_bits) e = E_EOF;
@@ -1028,35 +1068,37 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
         b.hi = b.hi > t1 ? b.hi : t1;
         b.hi = b.hi > asked ? b.hi : asked;
         if (e) {
-          ln.err = e;
-          ln.state = S_DONE;
+          err = e;
+          state = S_DONE;
         } else {
           b.bitpos = t3;
           if (sym < 256u) {
-            ln.lit_acc |= sym << (8u * ln.lit_n);
-            ++ln.lit_n;
-            ++ln.opos;
+            const uint64_t put = (uint64_t)sym << (8u * lit_n);
+            lit_lo |= (uint32_t)put;
+            lit_hi |= (uint32_t)(put >> 32);
+            ++lit_n;
+            ++opos;
           }
-          ln.match_len = base + ((w >> len) & ((1u << n) - 1u));
-          ln.state = sym < 256u ? S_SYM : (sym == 256u ? S_BLOCK : S_DIST);  // 256: finish_block
+          match_len = base + ((w >> len) & ((1u << n) - 1u));
+          state = sym < 256u ? S_SYM : (sym == 256u ? S_BLOCK : S_DIST);  // 256: finish_block
         }
       }
     }
     // read_literal (:631-684): distance symbol + extra -- in the step that decoded the length
     // whenever the window still holds the 28 bits this may take (one dword crossing per step)
     const uint32_t off2 = b.bitpos - b.widx * 32u;
-    if (ln.state == S_DIST && last_chunk && off2 <= 35u) {
-      const uint32_t w = (uint32_t)(win >> off2);  // >= 29 valid bits
+    if (state == S_DIST && last_chunk && off2 <= 67u) {
+      const uint32_t w = sb_window(b, off2);  // >= 29 real bits
       uint32_t d;
-      const uint32_t len = canon_decode<false>(L, w, kOffDistSorted, kOffDistMeta, ln.dist_lim, &d);
+      const uint32_t len = canon_decode<false>(L, w, kOffDistSorted, kOffDistMeta, dist_lim, &d);
       const bool nocode = len > 15u;
       const uint32_t nb = d < 4u ? 0u : (d - 2u) >> 1;
       const uint32_t dist =
           d < 4u ? d + 1u : (1u << (nb + 1u)) + 1u + ((d & 1u) << nb) + ((w >> len) & ((1u << nb) - 1u));
-      const uint32_t t1 = b.bitpos + (uint32_t)ln.dist_min, t2 = b.bitpos + len, t3 = t2 + nb;
-      const uint32_t hist = ln.opos < 32768u ? ln.opos : 32768u;  // hist_size
+      const uint32_t t1 = b.bitpos + (uint32_t)dist_min, t2 = b.bitpos + len, t3 = t2 + nb;
+      const uint32_t hist = opos < 32768u ? opos : 32768u;  // hist_size
       int e = 0;
-      if (ln.match_len > ln.out_cap - ln.opos) e = E_OUT_SMALL;
+      if (match_len > out_cap - opos) e = E_OUT_SMALL;
       if (dist > hist) e = E_CORRUPT;
       if (t3 > b.in_bits) e = E_EOF;
       if (d >= (uint32_t)kMaxDist) e = E_CORRUPT;
@@ -1067,38 +1109,40 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
       b.hi = b.hi > t1 ? b.hi : t1;
       b.hi = b.hi > asked ? b.hi : asked;
       if (e) {
-        ln.err = e;
-        ln.state = S_DONE;
+        err = e;
+        state = S_DONE;
       } else {
         b.bitpos = t3;
         new_match = true;
         new_dist = dist;
-        ln.state = S_SYM;
+        state = S_SYM;
       }
     }
 
     // (2) consume what the previous step requested (the only wait on global memory): advance the
     // bit window, then the stores -- copy (copy_history :689 / write_copy), literals
-    const bool crossed = (b.bitpos >> 5) != b.widx;
-    if (crossed) {
-      b.w0 = b.w1;
-      b.w1 = b.nxt;
-      ++b.widx;
+    const uint32_t crossed = (b.bitpos >> 5) - b.widx;  // 0, 1 or 2 dwords
+    if (crossed != 0) {
+      const uint32_t o1 = b.w1, o2 = b.w2, o3 = b.n0, o4 = b.n1;  // (values first, see sb_window)
+      b.w0 = crossed == 1u ? o1 : o2;
+      b.w1 = crossed == 1u ? o2 : o3;
+      b.w2 = crossed == 1u ? o3 : o4;
+      b.widx += crossed;
     }
     // Every lane-store is its own cache line, so stores are kept few and wide.  A store may
     // write (inside the stream's slot) past the bytes that are final: the lane's next store starts
     // right after the final ones and overwrites the rest, and nothing reads them before that.
     if (k != 0) {
-      uint8_t *dst = ln.out + copy_dst;
-      if (copy_dst + 8u <= ln.out_cap) {
-        const uint64_t v = ((uint64_t)ln.pend_hi << 32) | ln.pend_lo;
+      uint8_t *dst = out + copy_dst;
+      if (copy_dst + 8u <= out_cap) {
+        const uint64_t v = ((uint64_t)pend_hi << 32) | pend_lo;
         __builtin_memcpy(dst, &v, 8);
       } else {
-        uint32_t v = ln.pend_lo;
+        uint32_t v = pend_lo;
         if (k & 4u) {
           __builtin_memcpy(dst, &v, 4);
           dst += 4;
-          v = ln.pend_hi;
+          v = pend_hi;
         }
         if (k & 2u) {
           const uint16_t h = (uint16_t)v;
@@ -1108,44 +1152,50 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
         }
         if (k & 1u) *dst = (uint8_t)v;  // (k == 8 always has room: the copy was checked to fit)
       }
-      ln.copy_len -= k;
+      copy_len -= k;
     }
-    // literals collect in a register: one dword store per four, or when something else follows
-    if (ln.lit_n != 0 && (ln.lit_n == 4u || ln.state != S_SYM || new_match)) {
-      uint8_t *dst = ln.out + ln.opos - ln.lit_n;
-      if (ln.opos - ln.lit_n + 4u <= ln.out_cap) {
-        __builtin_memcpy(dst, &ln.lit_acc, 4);
+    // literals collect in a register pair: one 8-byte store once there are four or more, or when
+    // something else follows
+    if (lit_n != 0 && (lit_n >= 4u || state != S_SYM || new_match)) {
+      uint8_t *dst = out + opos - lit_n;
+      const uint64_t acc = ((uint64_t)lit_hi << 32) | lit_lo;
+      if (opos - lit_n + 8u <= out_cap) {
+        __builtin_memcpy(dst, &acc, 8);
       } else {
-        for (uint32_t i = 0; i < ln.lit_n; ++i) dst[i] = (uint8_t)(ln.lit_acc >> (8u * i));
+        for (uint32_t i = 0; i < lit_n; ++i) dst[i] = (uint8_t)(acc >> (8u * i));
       }
-      ln.lit_n = 0;
-      ln.lit_acc = 0;
+      lit_n = 0;
+      lit_lo = lit_hi = 0;
     }
     if (new_match) {
-      ln.copy_len = ln.match_len;
-      ln.copy_dist = new_dist;
+      copy_len = match_len;
+      copy_dist = new_dist;
     }
     // (3) loads for the next step
-    if (crossed) b.nxt = sb_load(b, b.widx + 2);
-    if (ln.state != S_STORED && ln.copy_len != 0) {
-      const uint8_t *src = ln.out + ln.opos - ln.copy_dist;
-      if (ln.opos - ln.copy_dist + 8u <= ln.out_cap) {  // the 8-byte read stays inside this stream's slot
-        ln.pend_lo = ld32g(src);
-        ln.pend_hi = ld32g(src + 4);
+    if (crossed != 0) {
+      const uint64_t v = sb_load2(b, b.widx + 3);
+      b.n0 = (uint32_t)v;
+      b.n1 = (uint32_t)(v >> 32);
+    }
+    if (state != S_STORED && copy_len != 0) {
+      const uint8_t *src = out + opos - copy_dist;
+      if (opos - copy_dist + 8u <= out_cap) {  // the 8-byte read stays inside this stream's slot
+        pend_lo = ld32g(src);
+        pend_hi = ld32g(src + 4);
       } else {
-        uint32_t n = ln.copy_len < ln.copy_dist ? ln.copy_len : ln.copy_dist;
+        uint32_t n = copy_len < copy_dist ? copy_len : copy_dist;
         if (n > 8u) n = 8u;
         uint64_t v = 0;
         for (uint32_t i = 0; i < n; ++i) v |= (uint64_t)src[i] << (8 * i);
-        ln.pend_lo = (uint32_t)v;
-        ln.pend_hi = (uint32_t)(v >> 32);
+        pend_lo = (uint32_t)v;
+        pend_hi = (uint32_t)(v >> 32);
       }
     }
   }
   if (have) {
-    P.out_len[sid] = ln.opos;
-    P.status[sid] = ln.err;
-    P.err_off[sid] = ln.err == E_CORRUPT ? (long long)sb_roffset(b) : -1;
+    P.out_len[sid] = opos;
+    P.status[sid] = err;
+    P.err_off[sid] = err == E_CORRUPT ? (long long)sb_roffset(b) : -1;
   }
 }
 template __global__ void inflate_simt_kernel<64>(InfParams);
