@@ -233,6 +233,24 @@ def bench_inflate(args, flate, eng, d_in, in_off, n, blen, world, rank, dev, dis
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ok = bool((status == 0).all()) and bool(torch.equal(out, d_in))  # round-trip property, full size
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import numpy as np
+        from oracle import pyoracle
+        ns = min(args.cpu_sample_streams * 4, n)  # the decoder is several times faster than the encoder
+        cores = min(os.cpu_count() or 1, 16)
+        h_off = np.asarray(coff[:ns + 1], dtype=np.uint64)
+        h_comp = comp[:int(h_off[-1])].cpu().numpy()
+        t1 = time.perf_counter()
+        _, _, o_len, o_st = pyoracle.inflate_batch(h_comp, h_off, [blen] * ns, nthreads=cores)
+        cdt = time.perf_counter() - t1
+        if int(o_st.any()) or int((o_len != blen).any()):
+            raise SystemExit("oracle inflate failed on the sample")
+        cpu_baseline = {
+            "value": round(ns * blen / cdt / 2**30, 4), "unit": "GiB/s", "cores": cores, "kind": "port",
+            "sample": "first %d of %d streams (%d MiB out), oracle C restatement, %d threads, %.1f s wall"
+                      % (ns, n, ns * blen >> 20, cores, cdt),
+        }
     if rank == 0:
         clen = int(coff[-1])
         k_ms = ms / args.steps
@@ -245,10 +263,11 @@ def bench_inflate(args, flate, eng, d_in, in_off, n, blen, world, rank, dev, dis
             "data": "synthetic",
             "config": {"workload": "inflate %d x %d B streams per GPU, S-%s, output == input: %s"
                                    % (n, blen, args.kind, ok), "stage_ms": {"inflate": round(k_ms, 3)}},
-            "roofline": {"bound": "hbm", "kernel": "inflate_kernel", "achieved": round(achieved, 2),
+            "roofline": {"bound": "hbm", "kernel": "inflate_simt_kernel" if n >= 2048 else "inflate_kernel",
+                         "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": None},
-            "cpu_baseline": None}))
+            "cpu_baseline": cpu_baseline}))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

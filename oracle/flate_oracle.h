@@ -119,6 +119,11 @@ size_t orc_deflate_bound(size_t n);
  * bytes read (roffset), *err_off = offset reported by corrupt_input_error. */
 int orc_inflate_stream(const uint8_t *in, size_t n, uint8_t *out, size_t cap,
                        size_t *out_len, size_t *consumed, long long *err_off);
+/* The same for n independent streams over nthreads host threads; stream i is
+ * in[in_off[i]..in_off[i+1]) -> out[out_off[i]..out_off[i+1]) (capacity).  Returns the first
+ * non-zero status. */
+int orc_inflate_batch(const uint8_t *in, const uint64_t *in_off, uint32_t n_streams, uint8_t *out,
+                      const uint64_t *out_off, uint64_t *out_len, int32_t *status, int nthreads);
 
 #ifdef __cplusplus
 }

@@ -449,3 +449,62 @@ int orc_inflate_stream(const uint8_t *in, size_t n, uint8_t *out, size_t cap,
   if (err_off) *err_off = f->err_off;
   return f->err;
 }
+
+/* ---- batch driver: independent streams over a few host threads (bench.py's cpu_baseline leg
+ * and the full-size property tests; the decoder itself is orc_inflate_stream above) ---- */
+#include <pthread.h>
+#include <stdlib.h>
+
+typedef struct {
+  const uint8_t *in;
+  const uint64_t *in_off;
+  uint8_t *out;
+  const uint64_t *out_off;
+  uint64_t *out_len;
+  int32_t *status;
+  uint32_t lo, hi;
+} inf_job;
+
+static void *inf_worker(void *arg) {
+  inf_job *j = (inf_job *)arg;
+  for (uint32_t i = j->lo; i < j->hi; i++) {
+    size_t n = 0, used = 0;
+    long long eo = -1;
+    const int rc = orc_inflate_stream(j->in + j->in_off[i], (size_t)(j->in_off[i + 1] - j->in_off[i]),
+                                      j->out + j->out_off[i], (size_t)(j->out_off[i + 1] - j->out_off[i]),
+                                      &n, &used, &eo);
+    j->out_len[i] = n;
+    j->status[i] = rc;
+  }
+  return NULL;
+}
+
+int orc_inflate_batch(const uint8_t *in, const uint64_t *in_off, uint32_t n_streams, uint8_t *out,
+                      const uint64_t *out_off, uint64_t *out_len, int32_t *status, int nthreads) {
+  if (nthreads < 1) nthreads = 1;
+  if ((uint32_t)nthreads > n_streams && n_streams > 0) nthreads = (int)n_streams;
+  pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+  inf_job *jobs = (inf_job *)calloc((size_t)nthreads, sizeof(inf_job));
+  for (int t = 0; t < nthreads; t++) {
+    inf_job *j = &jobs[t];
+    j->in = in;
+    j->in_off = in_off;
+    j->out = out;
+    j->out_off = out_off;
+    j->out_len = out_len;
+    j->status = status;
+    j->lo = (uint32_t)((uint64_t)n_streams * (uint64_t)t / (uint64_t)nthreads);
+    j->hi = (uint32_t)((uint64_t)n_streams * (uint64_t)(t + 1) / (uint64_t)nthreads);
+    if (nthreads > 1)
+      pthread_create(&th[t], NULL, inf_worker, j);
+    else
+      inf_worker(j);
+  }
+  int rc = 0;
+  for (int t = 0; t < nthreads; t++)
+    if (nthreads > 1) pthread_join(th[t], NULL);
+  for (uint32_t i = 0; i < n_streams && !rc; i++) rc = status[i];
+  free(th);
+  free(jobs);
+  return rc;
+}

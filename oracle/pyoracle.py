@@ -69,6 +69,9 @@ def lib():
         L.orc_deflate_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.orc_deflate_batch.restype = C.c_int
+        L.orc_inflate_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_inflate_batch.restype = C.c_int
         for name in ("orc_token_offset", "orc_token_length", "orc_token_literal",
                      "orc_reverse16", "orc_hash"):
             getattr(L, name).argtypes = [C.c_uint32]
@@ -134,6 +137,22 @@ def inflate(data, max_out, full=False):
     if rc != 0:
         raise RuntimeError("oracle inflate failed: rc=%d off=%d" % (rc, err_off.value))
     return res
+
+
+def inflate_batch(in_buf, in_off, out_sizes, nthreads=1):
+    """Independent DEFLATE streams -> (out_buf, out_off[N+1], out_len[N], status[N])."""
+    L = lib()
+    src = _as_u8(in_buf)
+    in_off = np.ascontiguousarray(in_off, dtype=np.uint64)
+    n = in_off.size - 1
+    out_off = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum(np.asarray(out_sizes, dtype=np.uint64), out=out_off[1:])
+    out = np.empty(max(int(out_off[-1]), 1), dtype=np.uint8)
+    out_len = np.zeros(n, dtype=np.uint64)
+    status = np.zeros(n, dtype=np.int32)
+    L.orc_inflate_batch(src.ctypes.data, in_off.ctypes.data, n, out.ctypes.data, out_off.ctypes.data,
+                        out_len.ctypes.data, status.ctypes.data, nthreads)
+    return out, out_off, out_len, status
 
 
 class DeflateFast:

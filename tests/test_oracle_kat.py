@@ -253,3 +253,24 @@ def test_inflate_accepts_zlib_streams(oracle):
         co = zlib.compressobj(level, zlib.DEFLATED, -15)
         c = co.compress(data) + co.flush()
         assert oracle.inflate(c, len(data)) == data
+
+
+def test_oracle_inflate_batch_matches_single_stream_decoder(oracle):
+    """orc_inflate_batch (threads) == orc_inflate_stream per stream, including the error codes."""
+    import numpy as np
+    from util import make_streams
+    data, off = make_streams([("text", 20000), ("ramp", 70000), ("zero", 300), ("rand", 5000), ("text", 0)], seed=5)
+    blobs = [oracle.deflate(data[int(off[i]):int(off[i + 1])]) for i in range(len(off) - 1)]
+    blobs.append(blobs[0][:-9])           # truncated -> unexpected EOF
+    blobs.append(b"\x07" + blobs[1][1:])  # block type 3 -> corrupt
+    sizes = [int(off[i + 1] - off[i]) for i in range(len(off) - 1)] + [20000, 70000]
+    coff = np.zeros(len(blobs) + 1, np.uint64)
+    np.cumsum([len(b) for b in blobs], out=coff[1:])
+    comp = np.frombuffer(b"".join(blobs), dtype=np.uint8)
+    out, ooff, olen, status = oracle.inflate_batch(comp, coff, sizes, nthreads=3)
+    for i, blob in enumerate(blobs):
+        rc, res, _, _ = oracle.inflate(blob, sizes[i], full=True)
+        assert status[i] == rc
+        assert olen[i] == len(res)
+        assert bytes(out[int(ooff[i]):int(ooff[i]) + len(res)]) == res
+    assert list(status[:5]) == [0] * 5 and status[5] == oracle.E_UNEXPECTED_EOF and status[6] == oracle.E_CORRUPT
