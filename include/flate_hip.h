@@ -61,7 +61,9 @@ int flate_hip_set_stream(flate_hip_ctx *ctx, void *hip_stream);
  *   "resident_blocks"    persistent LDS-table wavefronts (default 5 per CU)
  *   "guest_min_streams"  batches smaller than this use one block per stream (default 4096)
  *   "inflate_simt_min_streams"  inflate batches at least this large decode one stream per LANE
- *                        (64 per wavefront) instead of one per wavefront (default 2048) */
+ *                        (64 per wavefront) instead of one per wavefront (default 2048)
+ *   "inflate_lanes"      streams per wavefront of that decoder: 0 = chosen from the batch size
+ *                        (default), or 16 / 32 / 64 */
 int flate_hip_set_option(flate_hip_ctx *ctx, const char *name, int64_t value);
 const char *flate_hip_strerror(int code);
 /* Text of the last HIP runtime error seen by this ctx ("" if none). */
@@ -96,7 +98,8 @@ int flate_hip_lz77_matches(flate_hip_ctx *ctx, const uint8_t *in, const uint64_t
 /* -- decode ---------------------------------------------------------------------
  * replaces: &Reader::new + read to EOF (inflate.mbt:305,382) for n_streams
  * independent DEFLATE streams.  Stream i is in[in_off[i]..in_off[i+1]); its output
- * goes to out[out_off[i] .. out_off[i+1]) (capacity); out_len[i] = bytes produced;
+ * goes to out[out_off[i] .. out_off[i+1]) (capacity; bytes of the slot beyond out_len[i] are
+ * unspecified afterwards); out_len[i] = bytes produced;
  * status[i] = 0 or a negative code; err_off[i] = input offset reported by
  * corrupt_input_error (or -1). Returns the first non-zero status. */
 int flate_hip_inflate_batch(flate_hip_ctx *ctx, const uint8_t *in, const uint64_t *in_off,
