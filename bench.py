@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--no-guests", action="store_true",
                     help="match finder with LDS-table blocks only (no L2-table guest blocks); the "
                          "configuration the PMC traffic figure in profiles/ was collected on")
+    ap.add_argument("--spliced", action="store_true",
+                    help="encode into ONE DEFLATE stream per GPU (flate_hip_deflate_fast_spliced, SURVEY 8f-3)")
     ap.add_argument("--inflate-lanes", type=int, default=0, choices=[0, 16, 32, 64],
                     help="inflate: streams per wavefront (0 = chosen from the batch size)")
     ap.add_argument("--mode", default="deflate", choices=["deflate", "inflate"],
@@ -111,7 +113,12 @@ def main():
 
     def step():
         nonlocal gathered
-        _, out_off = eng.deflate_batch(d_in, in_off, out=out)
+        if args.spliced:  # one DEFLATE stream per GPU; the gather then moves one "stream" per rank
+            import numpy as np
+            _, nbytes, _ = eng.deflate_spliced(d_in, in_off, out=out)
+            out_off = np.array([0, nbytes], dtype=np.uint64)
+        else:
+            _, out_off = eng.deflate_batch(d_in, in_off, out=out)
         if gather:  # north_star's exchange step: every rank ends up with every compressed shard
             gathered = shard.gather_compressed(dist, out, out_off,
                                                buf=None if gathered is None else gathered.buf)
@@ -144,7 +151,7 @@ def main():
 
     # parity spot check against the oracle (never part of the timed region)
     verified = 0
-    if rank == 0 and args.verify > 0:
+    if rank == 0 and args.verify > 0 and not args.spliced:  # (spliced output: tests/test_splice.py)
         from oracle import pyoracle
         o_cpu = out[:clen].cpu().numpy()
         idx = np.linspace(0, n - 1, min(args.verify, n)).astype(int)
@@ -184,7 +191,9 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "%d x %d B independent streams per GPU (%.3f GiB/GPU), S-%s, "
-                            "deflate-fast, bit-exact vs oracle" % (n, blen, in_bytes / 2**30, args.kind),
+                            "deflate-fast, bit-exact vs oracle%s"
+                            % (n, blen, in_bytes / 2**30, args.kind,
+                               ", spliced into ONE stream per GPU" if args.spliced else ""),
                 "streams_per_gpu": n, "stream_len": blen, "kind": args.kind,
                 "compressed_bytes_per_gpu": clen, "ratio": round(ratio, 4),
                 "gather": "rccl all_gather_into_tensor (padded)" if gather else "none",

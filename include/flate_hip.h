@@ -107,13 +107,32 @@ int flate_hip_inflate_batch(flate_hip_ctx *ctx, const uint8_t *in, const uint64_
                             uint64_t *out_len, int32_t *status, int64_t *err_off,
                             uint32_t flags);
 
+/* -- splice ---------------------------------------------------------------------
+ * SURVEY 8(f)-3; no counterpart in the reference, whose Writer makes one stream per
+ * Writer.  Same compression as flate_hip_deflate_fast_batch (stream i is encoded as a
+ * fresh Writer would: writer.mbt:10,45; deflate.mbt:92,280), but the whole batch comes
+ * out as ONE legal DEFLATE stream that inflates to the concatenation of the inputs:
+ * every block starts at the bit where the previous stream's last block ended, stored
+ * blocks are padded relative to the spliced stream (write_stored_header -> flush,
+ * huffman-bit-writer.mbt:474-487,139-158) and the closing block of Writer::close
+ * (deflate.mbt:171-176: empty stored block, BFINAL=1) is written once, at the end.
+ * All other blocks carry BFINAL=0 (deflate.mbt:251,267,269).  *out_len = bytes of the
+ * stream; bit_off (host, n_streams+1 entries, may be NULL) = bit position of every
+ * stream's first block (the stream index a parallel decoder needs).  out_cap must be
+ * at least the result + 3 bytes (sum of flate_hip_deflate_bound is always enough); out
+ * is zeroed up to out_cap. */
+int flate_hip_deflate_fast_spliced(flate_hip_ctx *ctx, const uint8_t *in,
+                                   const uint64_t *in_off, uint32_t n_streams, uint8_t *out,
+                                   uint64_t out_cap, uint64_t *out_len, uint64_t *bit_off,
+                                   uint32_t flags);
+
 /* -- measurement ----------------------------------------------------------------
  * With profiling on, every kernel launch of the next call is bracketed by HIP
  * events on the launch stream; flate_hip_last_timing returns the per-stage
  * milliseconds of the last call (stage names via flate_hip_stage_name). */
 #define FLATE_HIP_STAGE_LZ77 0
 #define FLATE_HIP_STAGE_HUFF_PACK 1
-#define FLATE_HIP_STAGE_COMPACT 2
+#define FLATE_HIP_STAGE_COMPACT 2 /* unused: the pack kernel writes in place */
 #define FLATE_HIP_STAGE_INFLATE 3
 #define FLATE_HIP_STAGE_COUNT 4
 int flate_hip_set_profiling(flate_hip_ctx *ctx, int on);

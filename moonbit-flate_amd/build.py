@@ -10,7 +10,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libflate_hip.so")
 
 SOURCES = ["lz77_kernels.hip", "huff_pack_kernels.hip", "compact_kernels.hip",
-           "inflate_kernels.hip", "flate_api.hip", "synth.cpp"]
+           "inflate_kernels.hip", "splice_kernels.hip", "flate_api.hip", "synth.cpp"]
 HEADERS = ["flate_common.h", "flate_kernels.h", os.path.join(ROOT, "include", "flate_hip.h")]
 
 

@@ -48,6 +48,8 @@ struct flate_hip_ctx {
   int guest_blocks = 0;      // 0 = guest kernel off
   float guest_share = 0.f;   // fraction of the single-window streams given to the guests
   uint32_t guest_min = 4096; // below this many streams the guests stay idle
+  int32_t h_status_word = 0;  // landing pads of small async D2H copies
+  uint64_t h_total_bytes = 0;
   uint32_t num_cus = 256;
   int inflate_lanes = 0;  // streams per wavefront of that inflater: 0 = by batch size, or 16/32/64
   uint32_t inflate_simt_min = 2048;  // batches at least this large use the lane-per-stream inflater
@@ -411,15 +413,13 @@ size_t flate_hip_deflate_bound(size_t n) {
   return n * 2 + windows * 320 + 16;
 }
 
-int flate_hip_deflate_fast_batch(flate_hip_ctx *c, const uint8_t *in, const uint64_t *in_off,
-                                 uint32_t n, uint8_t *out, uint64_t out_cap, uint64_t *out_off,
-                                 uint32_t flags) {
-  if (!c || !in_off || !out_off || (n && (!in || !out))) return FLATE_HIP_E_INVALID;
-  c->hip_err.clear();
-  if (n == 0) {
-    out_off[0] = 0;
-    return FLATE_HIP_OK;
-  }
+}  // extern "C"
+
+// Both encode entry points.  spliced: the whole batch becomes one DEFLATE stream; out_off then
+// receives the bit position of every stream (may be NULL) and *total_bytes the size.
+static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *in_off, uint32_t n,
+                          uint8_t *out, uint64_t out_cap, uint64_t *out_off, uint32_t flags,
+                          bool spliced, uint64_t *total_bytes) {
   HIP_TRY(c, hipSetDevice(c->device));
   StagePlan pl;
   int rc = make_plan(in_off, n, pl);
@@ -446,6 +446,10 @@ int flate_hip_deflate_fast_batch(flate_hip_ctx *c, const uint8_t *in, const uint
   if ((rc = ensure(c, c->d_blk_meta, nb * 16))) return rc;
   if ((rc = ensure(c, c->d_out_len, (size_t)n * 8 + 8))) return rc;
   if ((rc = ensure(c, c->d_out_off, ((size_t)n + 1) * 8))) return rc;
+  if (spliced) {
+    if ((rc = ensure(c, c->d_slot_off, ((size_t)n + 1) * 16))) return rc;  // stream summaries {a, b}
+    HIP_TRY(c, hipMemsetAsync(d_out, 0, out_cap, c->stream));  // shared dwords are OR-ed in
+  }
   HIP_TRY(c, hipMemcpyAsync(c->d_blk_base.p, pl.blk_base.data(), ((size_t)n + 1) * 4,
                             hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemsetAsync(c->d_status.p, 0, 4, c->stream));
@@ -462,6 +466,9 @@ int flate_hip_deflate_fast_batch(flate_hip_ctx *c, const uint8_t *in, const uint
   H.blk_cl = (uint32_t *)c->d_blk_cl.p;
   H.blk_hdr = (uint32_t *)c->d_blk_hdr.p;
   H.blk_meta = (uint4 *)c->d_blk_meta.p;
+  H.spliced = spliced ? 1u : 0u;
+  H.stream_sum = spliced ? (uint64_t *)c->d_slot_off.p : nullptr;
+  H.stream_bit = spliced ? (const uint64_t *)c->d_out_off.p : nullptr;
   H.out_len = (uint64_t *)c->d_out_len.p;
   H.out_off = (const uint64_t *)c->d_out_off.p;
   H.out = d_out;
@@ -478,23 +485,76 @@ int flate_hip_deflate_fast_batch(flate_hip_ctx *c, const uint8_t *in, const uint
     StageTimer t(c, FLATE_HIP_STAGE_HUFF_PACK);
     hipLaunchKernelGGL(huff_hist_kernel, dim3(n), dim3(64), 0, c->stream, H);
     hipLaunchKernelGGL(huff_code_kernel, dim3(n), dim3(64), 0, c->stream, H);
-    hipLaunchKernelGGL(scan_sizes_kernel, dim3(1), dim3(1024), 0, c->stream, C);
+    if (!spliced) {
+      hipLaunchKernelGGL(scan_sizes_kernel, dim3(1), dim3(1024), 0, c->stream, C);
+    } else {
+      SpliceParams S;
+      S.sum = (const uint64_t *)c->d_slot_off.p;
+      S.stream_bit = (uint64_t *)c->d_out_off.p;
+      S.total_bytes = (uint64_t *)c->d_out_len.p + n;  // (d_out_len has n + 1 slots)
+      S.out_cap = out_cap;
+      S.status = (int *)c->d_status.p;
+      S.n_streams = n;
+      hipLaunchKernelGGL(splice_scan_kernel, dim3(1), dim3(1024), 0, c->stream, S);
+    }
     hipLaunchKernelGGL(huff_pack_kernel, dim3(n), dim3(64), 0, c->stream, H);
   }
   HIP_TRY(c, hipGetLastError());
 
-  int status = 0;
-  HIP_TRY(c, hipMemcpyAsync(out_off, c->d_out_off.p, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost,
-                            c->stream));
-  HIP_TRY(c, hipMemcpyAsync(&status, c->d_status.p, 4, hipMemcpyDeviceToHost, c->stream));
+  uint64_t produced = 0;
+  if (out_off)
+    HIP_TRY(c, hipMemcpyAsync(out_off, c->d_out_off.p, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost,
+                              c->stream));
+  if (spliced)
+    HIP_TRY(c, hipMemcpyAsync(&c->h_total_bytes, (uint64_t *)c->d_out_len.p + n, 8, hipMemcpyDeviceToHost,
+                              c->stream));
+  HIP_TRY(c, hipMemcpyAsync(&c->h_status_word, c->d_status.p, 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if (status) return status;
+  if (c->h_status_word) return c->h_status_word;
+  produced = spliced ? c->h_total_bytes : out_off[n];
+  if (total_bytes) *total_bytes = produced;
   if (!dev) {
-    HIP_TRY(c, hipMemcpyAsync(out, c->d_out.p, out_off[n], hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_out.p, produced, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
   }
   const bool used[FLATE_HIP_STAGE_COUNT] = {true, true, false, false};
   return collect_timing(c, used);
+}
+
+extern "C" {
+
+int flate_hip_deflate_fast_batch(flate_hip_ctx *c, const uint8_t *in, const uint64_t *in_off,
+                                 uint32_t n, uint8_t *out, uint64_t out_cap, uint64_t *out_off,
+                                 uint32_t flags) {
+  if (!c || !in_off || !out_off || (n && (!in || !out))) return FLATE_HIP_E_INVALID;
+  c->hip_err.clear();
+  if (n == 0) {
+    out_off[0] = 0;
+    return FLATE_HIP_OK;
+  }
+  return deflate_common(c, in, in_off, n, out, out_cap, out_off, flags, false, nullptr);
+}
+
+int flate_hip_deflate_fast_spliced(flate_hip_ctx *c, const uint8_t *in, const uint64_t *in_off,
+                                   uint32_t n, uint8_t *out, uint64_t out_cap, uint64_t *out_len,
+                                   uint64_t *bit_off, uint32_t flags) {
+  if (!c || !in_off || !out || !out_len || (n && !in)) return FLATE_HIP_E_INVALID;
+  c->hip_err.clear();
+  if (n == 0) {  // nothing but the closing block of Writer::close
+    static const uint8_t closing[5] = {0x01, 0x00, 0x00, 0xff, 0xff};
+    if (out_cap < 5) return FLATE_HIP_E_OUT_TOO_SMALL;
+    if (flags & FLATE_HIP_DEVICE_PTRS) {
+      HIP_TRY(c, hipSetDevice(c->device));
+      HIP_TRY(c, hipMemcpyAsync(out, closing, 5, hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+    } else {
+      memcpy(out, closing, 5);
+    }
+    *out_len = 5;
+    if (bit_off) bit_off[0] = 0;
+    return FLATE_HIP_OK;
+  }
+  return deflate_common(c, in, in_off, n, out, out_cap, bit_off, flags, true, out_len);
 }
 
 int flate_hip_lz77_matches(flate_hip_ctx *c, const uint8_t *in, const uint64_t *in_off, uint32_t n,

@@ -42,6 +42,10 @@ struct HuffParams {
   uint32_t *blk_cl;    // per block 320 u32: (len << 16) | bit-reversed code, same layout
   uint32_t *blk_hdr;   // per block 704 u32: dynamic-header items (nbits << 16) | value
   uint4 *blk_meta;     // per block {kind 0 stored / 1 huffman-only / 2 dynamic, header items, start bit lo, hi}
+  // spliced mode (one DEFLATE stream for the whole batch, splice_kernels.hip); 0/NULL otherwise
+  uint32_t spliced;
+  uint64_t *stream_sum;          // per stream {a, b}: written by huff_code_kernel
+  const uint64_t *stream_bit;    // n_streams + 1: read by huff_pack_kernel
   uint64_t *out_len;   // exact compressed bytes per stream (huff_code_kernel)
   const uint64_t *out_off;  // exclusive scan of out_len
   uint8_t *out;
@@ -81,6 +85,17 @@ __global__ void scan_sizes_kernel(CompactParams P);
 __global__ void inflate_kernel(InfParams P);
 template <int LPW>
 __global__ void inflate_simt_kernel(InfParams P);
+
+// splice (splice_kernels.hip): bit positions of the streams inside one spliced DEFLATE stream
+struct SpliceParams {
+  const uint64_t *sum;    // per stream {a, b} written by huff_code_kernel (see splice_kernels.hip)
+  uint64_t *stream_bit;   // n_streams + 1
+  uint64_t *total_bytes;  // size of the spliced stream
+  uint64_t out_cap;
+  int *status;            // -2 if total_bytes > out_cap
+  uint32_t n_streams;
+};
+__global__ void splice_scan_kernel(SpliceParams P);
 size_t inflate_simt_lds_bytes(int lanes_per_wave);  // dynamic LDS of that launch
 
 }  // namespace flate

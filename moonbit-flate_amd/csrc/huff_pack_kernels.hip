@@ -126,9 +126,15 @@ struct BitSink {
   uint32_t head;     // bytes of dword 0 that belong to the previous stream (0..3)
   uint32_t last_dw;  // dword holding the stream's last byte
   uint32_t tail;     // bytes of last_dw that belong to this stream (1..4)
+  bool bit_edges;    // spliced mode: dword 0 and last_dw are shared with the neighbouring streams
+                     // at bit granularity and OR-ed atomically into the zeroed destination
 };
 
 FLATE_D void sink_store(const BitSink &S, uint32_t idx, uint32_t v) {
+  if (S.bit_edges && (idx == 0 || idx == S.last_dw)) {
+    if (v) atomicOr(&S.out32[idx], v);
+    return;
+  }
   const bool first = idx == 0 && S.head != 0;
   const bool last = idx == S.last_dw && S.tail != 4;
   if (!first && !last) {
@@ -708,6 +714,9 @@ __global__ __launch_bounds__(64) void huff_code_kernel(HuffParams P) {
   if (sid >= P.n_streams) return;
   const BlockGeom g = block_geom(P, sid);
   uint64_t bitpos = 0;
+  // spliced mode (splice_kernels.hip): x -> x + sum_a, or x -> align8(x + sum_a) + sum_b once a
+  // stored block has been seen
+  uint64_t sum_a = 0, sum_b = ~0ull;
   for (uint32_t b = 0; b < g.nblocks; ++b) {
     const int n = b < g.full ? kMaxStoreBlockSize : g.r;
     const uint32_t gb = g.blk0 + b;
@@ -772,8 +781,15 @@ __global__ __launch_bounds__(64) void huff_code_kernel(HuffParams P) {
     const uint64_t start = bitpos;
     if (kind == 0) {  // write_stored_header + write_bytes (:474-487,202-225)
       bitpos = ((bitpos + 3 + 7) & ~7ull) + 32 + 8ull * (uint64_t)n;
+      if (sum_b == ~0ull) {
+        sum_a += 3;
+        sum_b = 32 + 8ull * (uint64_t)n;
+      } else {
+        sum_b = ((sum_b + 3 + 7) & ~7ull) + 32 + 8ull * (uint64_t)n;
+      }
     } else {
       bitpos += bits;
+      if (sum_b == ~0ull) sum_a += bits; else sum_b += bits;
     }
     if (lane == 0)
       P.blk_meta[gb] = make_uint4((uint32_t)kind, kind ? sh.hdr_n : 0u, (uint32_t)start, (uint32_t)(start >> 32));
@@ -781,7 +797,13 @@ __global__ __launch_bounds__(64) void huff_code_kernel(HuffParams P) {
   }
   // Compressor::close: empty stored block with BFINAL, then flush (deflate.mbt:171-176)
   bitpos = ((bitpos + 3 + 7) & ~7ull) + 32;
-  if (lane == 0) P.out_len[sid] = bitpos >> 3;
+  if (lane == 0) {
+    P.out_len[sid] = bitpos >> 3;
+    if (P.spliced) {
+      P.stream_sum[2 * (uint64_t)sid] = sum_a;
+      P.stream_sum[2 * (uint64_t)sid + 1] = sum_b;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -797,18 +819,37 @@ __global__ __launch_bounds__(64) void huff_pack_kernel(HuffParams P) {
 
   for (int i = lane; i < kRing; i += 64) sh.ring[i] = 0;
   __syncthreads();
-  uint8_t *dst = P.out + P.out_off[sid];
-  const uint64_t out_bytes = P.out_len[sid];
   BitSink S;
   S.ring = sh.ring;
-  S.head = (uint32_t)((uintptr_t)dst & 3u);
-  S.out32 = reinterpret_cast<uint32_t *>(dst - S.head);
-  S.bitpos = 8ull * S.head;
   S.flushed = 0;
-  {
+  S.bit_edges = P.spliced != 0;
+  uint64_t out_bits;  // what this stream must write
+  if (!P.spliced) {
+    uint8_t *dst = P.out + P.out_off[sid];
+    const uint64_t out_bytes = P.out_len[sid];
+    out_bits = 8 * out_bytes;
+    S.head = (uint32_t)((uintptr_t)dst & 3u);
+    S.out32 = reinterpret_cast<uint32_t *>(dst - S.head);
+    S.bitpos = 8ull * S.head;
     const uint64_t end_byte = S.head + out_bytes;  // exclusive, relative to out32
     S.last_dw = (uint32_t)((end_byte - 1) >> 2);
     S.tail = (uint32_t)(((end_byte - 1) & 3u) + 1u);
+  } else {
+    // one DEFLATE stream for the whole batch (splice_kernels.hip): this stream's blocks start at
+    // bit stream_bit[sid] of the output; only the last stream writes the closing block.  The
+    // sink's bit position is congruent to the position in the spliced stream mod 8, so the
+    // padding of stored blocks comes out relative to the spliced stream.
+    const uint64_t mis = (uint64_t)((uintptr_t)P.out & 3u);
+    const uint64_t g0 = P.stream_bit[sid] + 8 * mis;  // relative to the aligned dword grid of out
+    uint64_t g1 = P.stream_bit[sid + 1] + 8 * mis;
+    const bool last_stream = sid + 1 == P.n_streams;
+    if (last_stream) g1 = ((g1 + 3 + 7) & ~7ull) + 32;  // + closing block
+    out_bits = g1 - g0;
+    S.head = 0;
+    S.out32 = reinterpret_cast<uint32_t *>(P.out - mis) + (g0 >> 5);
+    S.bitpos = g0 & 31u;
+    S.last_dw = g1 > g0 ? (uint32_t)(((g1 - 1) >> 5) - (g0 >> 5)) : 0u;
+    S.tail = 4;  // (the batch's very last dword may reach 3 bytes past the result: out_cap covers it)
   }
   const uint64_t bit0 = S.bitpos;
 
@@ -887,10 +928,11 @@ __global__ __launch_bounds__(64) void huff_pack_kernel(HuffParams P) {
     const uint32_t eob = sh.lit_cl[kEndBlockMarker];
     sink_emit(S, eob & 0xffffu, lane == 0 ? (eob >> 16) : 0u, lane);
   }
-  emit_stored(S, g.stream, 0, true, lane);  // Compressor::close (deflate.mbt:171-176)
+  if (!P.spliced || sid + 1 == P.n_streams)
+    emit_stored(S, g.stream, 0, true, lane);  // Compressor::close (deflate.mbt:171-176)
   sink_finish(S, lane);
   // the sizes computed by huff_code_kernel and the bits actually written must agree
-  if (lane == 0 && ((S.bitpos - bit0) >> 3) != out_bytes) atomicExch(P.status, -3);
+  if (lane == 0 && S.bitpos - bit0 != out_bits) atomicExch(P.status, -3);
 }
 
 }  // namespace flate

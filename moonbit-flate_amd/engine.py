@@ -170,6 +170,33 @@ class FlateEngine:
             self._check(rc)
         return out, out_off, out_len, status, err_off
 
+    def deflate_spliced(self, data, in_off, out=None, compat_go=False):
+        """Compress the streams as deflate_batch does, but into ONE legal DEFLATE stream that
+        inflates to the concatenation of the inputs.
+        Returns (out, out_len, bit_off[N+1]): bit_off[i] = bit position of stream i's first block."""
+        in_off = np.ascontiguousarray(in_off, dtype=np.uint64)
+        n = in_off.size - 1
+        lens = in_off[1:] - in_off[:-1]
+        cap = int(sum(deflate_bound(int(l)) * int(c) for l, c in zip(*np.unique(lens, return_counts=True)))) + 16
+        bit_off = np.zeros(n + 1, dtype=np.uint64)
+        out_len = C.c_uint64(0)
+        device = _is_torch(data)
+        if device:
+            import torch
+            assert data.dtype == torch.uint8 and data.is_cuda and data.is_contiguous()
+            if out is None:
+                out = torch.empty(cap, dtype=torch.uint8, device=data.device)
+            in_ptr, out_ptr, out_cap = data.data_ptr(), out.data_ptr(), out.numel()
+        else:
+            data = np.ascontiguousarray(data, dtype=np.uint8)
+            if out is None:
+                out = np.zeros(cap, dtype=np.uint8)
+            in_ptr, out_ptr, out_cap = data.ctypes.data, out.ctypes.data, out.size
+        self._check(self._L.flate_hip_deflate_fast_spliced(
+            self._ctx, in_ptr, in_off.ctypes.data, n, out_ptr, out_cap, C.byref(out_len),
+            bit_off.ctypes.data, self._flags(compat_go, False, device)))
+        return out, int(out_len.value), bit_off
+
     def lz77_matches(self, data, in_off, compat_go=False, lz_serial=False):
         """Match finder only.  Returns a list over LZ77 chunks (stream order) of
         (pos uint32[], tok uint32[]) and the per-stream chunk counts."""

@@ -178,6 +178,49 @@ int orc_deflate_stream(const uint8_t *in, size_t n, const size_t *sizes, int nwr
   return rc;
 }
 
+/* SURVEY 8(f)-3 -- no counterpart in the reference, whose Writer makes one stream per Writer:
+ * the n streams of a batch as ONE legal DEFLATE stream.  Stream i is compressed exactly as a fresh
+ * Writer would (fresh DeflateFast: deflate.mbt:92, deflate-fast.mbt:111-117; a sync'ed enc_speed
+ * at its end as in close, deflate.mbt:163-166) but all streams share one HuffmanBitWriter, so a
+ * block starts at the bit where the previous stream's last block ended and a stored block is
+ * padded (write_stored_header -> flush, huffman-bit-writer.mbt:474-487,139-158) relative to the
+ * spliced stream; the closing empty stored block with BFINAL=1 (deflate.mbt:171-176) is written
+ * once, after the last stream.  Every other block has BFINAL=0 (deflate.mbt:251,267,269), which
+ * is what makes the concatenation legal.  bit_off (n+1 entries, optional) = bit position of each
+ * stream's first block ("stream index"). */
+int orc_deflate_spliced(const uint8_t *in, const uint64_t *in_off, uint32_t n_streams, uint8_t *out,
+                        size_t cap, size_t *out_len, uint64_t *bit_off, int compat) {
+  orc_sink sink = {out, 0, cap, 0};
+  compressor *d = (compressor *)malloc(sizeof(compressor));
+  if (!d) return ORC_E_INTERNAL;
+  orc_trace_reset();
+  int rc = compressor_init(d, &sink, compat);
+  for (uint32_t i = 0; i < n_streams && rc == 0; i++) {
+    if (bit_off) bit_off[i] = (uint64_t)orc_bw_bitpos(&d->w);
+    if (i > 0) { /* fresh Writer state for this stream; the bit writer goes on */
+      orc_df_free(d->best_speed);
+      d->best_speed = orc_df_new(compat);
+      if (!d->best_speed) rc = ORC_E_INTERNAL;
+    }
+    size_t nw;
+    if (rc == 0) rc = compressor_write(d, in + in_off[i], (size_t)(in_off[i + 1] - in_off[i]), &nw);
+    if (rc == 0) {
+      d->sync = 1;
+      enc_speed(d);
+      d->sync = 0;
+      rc = d->err;
+    }
+  }
+  if (rc == 0) {
+    if (bit_off) bit_off[n_streams] = (uint64_t)orc_bw_bitpos(&d->w);
+    rc = compressor_close(d);
+  }
+  *out_len = sink.len;
+  compressor_free(d);
+  free(d);
+  return rc;
+}
+
 /* Upper bound on the stream size for n input bytes: every window could be
  * emitted Huffman-coded at <= 15 bits/byte plus a <= 300-byte header; stored
  * blocks cost 5 bytes per 65535; plus the final empty stored block. */

@@ -125,6 +125,11 @@ int orc_inflate_stream(const uint8_t *in, size_t n, uint8_t *out, size_t cap,
 int orc_inflate_batch(const uint8_t *in, const uint64_t *in_off, uint32_t n_streams, uint8_t *out,
                       const uint64_t *out_off, uint64_t *out_len, int32_t *status, int nthreads);
 
+/* -- splice: the n streams of a batch compressed into ONE legal DEFLATE stream
+ * (compressor.c); out needs sum of orc_deflate_bound() bytes. */
+int orc_deflate_spliced(const uint8_t *in, const uint64_t *in_off, uint32_t n_streams, uint8_t *out,
+                        size_t cap, size_t *out_len, uint64_t *bit_off, int compat);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,6 +72,9 @@ def lib():
         L.orc_inflate_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_int]
         L.orc_inflate_batch.restype = C.c_int
+        L.orc_deflate_spliced.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t,
+                                          C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_deflate_spliced.restype = C.c_int
         for name in ("orc_token_offset", "orc_token_length", "orc_token_literal",
                      "orc_reverse16", "orc_hash"):
             getattr(L, name).argtypes = [C.c_uint32]
@@ -153,6 +156,23 @@ def inflate_batch(in_buf, in_off, out_sizes, nthreads=1):
     L.orc_inflate_batch(src.ctypes.data, in_off.ctypes.data, n, out.ctypes.data, out_off.ctypes.data,
                         out_len.ctypes.data, status.ctypes.data, nthreads)
     return out, out_off, out_len, status
+
+
+def deflate_spliced(in_buf, in_off, compat=COMPAT_MOONBIT):
+    """The streams of a batch as ONE legal DEFLATE stream -> (bytes, bit_off[N+1])."""
+    L = lib()
+    src = _as_u8(in_buf)
+    in_off = np.ascontiguousarray(in_off, dtype=np.uint64)
+    n = in_off.size - 1
+    cap = sum(L.orc_deflate_bound(int(in_off[i + 1] - in_off[i])) for i in range(n)) + 16
+    out = np.empty(cap, dtype=np.uint8)
+    bit_off = np.zeros(n + 1, dtype=np.uint64)
+    out_len = C.c_size_t(0)
+    rc = L.orc_deflate_spliced(src.ctypes.data, in_off.ctypes.data, n, out.ctypes.data, cap,
+                               C.byref(out_len), bit_off.ctypes.data, compat)
+    if rc != 0:
+        raise RuntimeError("oracle spliced deflate failed: %d" % rc)
+    return out[:out_len.value].tobytes(), bit_off
 
 
 class DeflateFast:
