@@ -218,9 +218,15 @@ def bench_inflate(args, flate, eng, d_in, in_off, n, blen, world, rank, dev, dis
     """Config 5: inflate-only.  Streams compressed once (untimed) by the encoder; one step = one
     inflate_batch over all of them; value = GiB/s of decompressed output."""
     import torch
-    comp, coff = eng.deflate_batch(d_in, in_off)
     sizes = [blen] * n
     out = torch.empty(n * blen, dtype=torch.uint8, device=dev)
+    if args.spliced:  # ONE compressed stream + its index, decoded in parallel (config 5 as worded)
+        comp, nbytes, bit_off = eng.deflate_spliced(d_in, in_off)
+        coff = [0, nbytes]
+        run = lambda: eng.inflate_spliced(comp, nbytes, bit_off, sizes, out=out)
+    else:
+        comp, coff = eng.deflate_batch(d_in, in_off)
+        run = lambda: eng.inflate_batch(comp, coff, sizes, out=out)
 
     def sync_all():
         if dist is not None:
@@ -228,12 +234,12 @@ def bench_inflate(args, flate, eng, d_in, in_off, n, blen, world, rank, dev, dis
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        eng.inflate_batch(comp, coff, sizes, out=out)
+        run()
     ms = 0.0
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        _, _, olen, status, _ = eng.inflate_batch(comp, coff, sizes, out=out)
+        _, _, olen, status, _ = run()
         ms += eng.last_timing()["inflate"]
     sync_all()
     dt = time.perf_counter() - t0
@@ -243,7 +249,7 @@ def bench_inflate(args, flate, eng, d_in, in_off, n, blen, world, rank, dev, dis
         dt = float(tt.item())
     ok = bool((status == 0).all()) and bool(torch.equal(out, d_in))  # round-trip property, full size
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.spliced:
         import numpy as np
         from oracle import pyoracle
         ns = min(args.cpu_sample_streams * 4, n)  # the decoder is several times faster than the encoder
@@ -270,8 +276,9 @@ def bench_inflate(args, flate, eng, d_in, in_off, n, blen, world, rank, dev, dis
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": "inflate %d x %d B streams per GPU, S-%s, output == input: %s"
-                                   % (n, blen, args.kind, ok), "stage_ms": {"inflate": round(k_ms, 3)}},
+            "config": {"workload": "inflate %s%d x %d B streams per GPU, S-%s, output == input: %s"
+                                   % ("ONE spliced stream of " if args.spliced else "", n, blen, args.kind, ok),
+                       "stage_ms": {"inflate": round(k_ms, 3)}},
             "roofline": {"bound": "hbm", "kernel": "inflate_simt_kernel" if n >= 2048 else "inflate_kernel",
                          "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),

@@ -107,6 +107,17 @@ int flate_hip_inflate_batch(flate_hip_ctx *ctx, const uint8_t *in, const uint64_
                             uint64_t *out_len, int32_t *status, int64_t *err_off,
                             uint32_t flags);
 
+/* The same for the n_streams pieces of ONE spliced stream in[0, in_len) (as written by
+ * flate_hip_deflate_fast_spliced): piece i starts at bit bit_off[i] (host array, n_streams+1
+ * entries) and is decoded on its own -- the encoder's pieces never reference one another --
+ * until the bit where piece i+1 starts; the last piece runs through the closing block.
+ * This is what a single Reader over the whole stream produces (inflate.mbt:305,382), cut at
+ * the index.  status[i] = E_CORRUPT also if the index does not point at block boundaries. */
+int flate_hip_inflate_spliced(flate_hip_ctx *ctx, const uint8_t *in, uint64_t in_len,
+                              const uint64_t *bit_off, uint32_t n_streams, uint8_t *out,
+                              const uint64_t *out_off, uint64_t *out_len, int32_t *status,
+                              int64_t *err_off, uint32_t flags);
+
 /* -- splice ---------------------------------------------------------------------
  * SURVEY 8(f)-3; no counterpart in the reference, whose Writer makes one stream per
  * Writer.  Same compression as flate_hip_deflate_fast_batch (stream i is encoded as a

@@ -600,26 +600,24 @@ int flate_hip_debug_lz_stamps(flate_hip_ctx *c, uint64_t *out, uint32_t max_chun
 }
 #endif
 
-int flate_hip_inflate_batch(flate_hip_ctx *c, const uint8_t *in, const uint64_t *in_off, uint32_t n,
-                            uint8_t *out, const uint64_t *out_off, uint64_t *out_len,
-                            int32_t *status, int64_t *err_off, uint32_t flags) {
-  if (!c || !in_off || !out_off || !out_len || !status || !err_off || (n && (!in || !out)))
-    return FLATE_HIP_E_INVALID;
-  c->hip_err.clear();
-  if (n == 0) return FLATE_HIP_OK;
-  for (uint32_t i = 0; i < n; ++i)
-    if (in_off[i + 1] < in_off[i] || out_off[i + 1] < out_off[i]) return FLATE_HIP_E_INVALID;
-  for (uint32_t i = 0; i < n; ++i)
-    if (in_off[i + 1] - in_off[i] >= 0x7ffe0000ull) return FLATE_HIP_E_TOO_LARGE;
+}  // extern "C"
+
+// Both decode entry points.  spliced_len != 0: `in` is ONE stream of that many bytes and in_off
+// holds the bit positions of its n pieces (flate_hip_inflate_spliced).
+static int inflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *in_off, uint32_t n,
+                          uint8_t *out, const uint64_t *out_off, uint64_t *out_len, int32_t *status,
+                          int64_t *err_off, uint32_t flags, uint64_t spliced_len) {
+  const bool spliced = spliced_len != 0;
+  const uint64_t in_bytes = spliced ? spliced_len : in_off[n];
   HIP_TRY(c, hipSetDevice(c->device));
   const bool dev = (flags & FLATE_HIP_DEVICE_PTRS) != 0;
   int rc;
   const uint8_t *d_in = in;
   uint8_t *d_out = out;
   if (!dev) {
-    if ((rc = ensure(c, c->d_in, in_off[n] + 16))) return rc;
+    if ((rc = ensure(c, c->d_in, in_bytes + 16))) return rc;
     if ((rc = ensure(c, c->d_out, out_off[n] + 16))) return rc;
-    HIP_TRY(c, hipMemcpyAsync(c->d_in.p, in, in_off[n], hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_in.p, in, in_bytes, hipMemcpyHostToDevice, c->stream));
     d_in = (const uint8_t *)c->d_in.p;
     d_out = (uint8_t *)c->d_out.p;
   }
@@ -639,13 +637,15 @@ int flate_hip_inflate_batch(flate_hip_ctx *c, const uint8_t *in, const uint64_t 
   I.status = (int32_t *)c->d_istatus.p;
   I.err_off = (int64_t *)c->d_ierr.p;
   I.n_streams = n;
+  I.bit_off = spliced ? (const uint64_t *)c->d_in_off.p : nullptr;
+  I.in_len = in_bytes;
   {
     StageTimer t(c, FLATE_HIP_STAGE_INFLATE);
     // large batches: one lane per stream (64 streams per wavefront); small ones: one wavefront
     // per stream
     // (its bit positions are 32-bit: every compressed stream must be < 256 MiB)
-    bool simt = n >= c->inflate_simt_min;
-    for (uint32_t i = 0; i < n && simt; ++i) simt = in_off[i + 1] - in_off[i] < (1ull << 28);
+    bool simt = spliced || n >= c->inflate_simt_min;
+    for (uint32_t i = 0; i < n && simt && !spliced; ++i) simt = in_off[i + 1] - in_off[i] < (1ull << 28);
     if (simt) {
       // streams per wavefront: as many as still leave four wavefronts (one per SIMD) per CU
       int lpw = c->inflate_lanes;
@@ -672,6 +672,38 @@ int flate_hip_inflate_batch(flate_hip_ctx *c, const uint8_t *in, const uint64_t 
   for (uint32_t i = 0; i < n; ++i)
     if (status[i]) return status[i];
   return FLATE_HIP_OK;
+}
+
+extern "C" {
+
+int flate_hip_inflate_batch(flate_hip_ctx *c, const uint8_t *in, const uint64_t *in_off, uint32_t n,
+                            uint8_t *out, const uint64_t *out_off, uint64_t *out_len,
+                            int32_t *status, int64_t *err_off, uint32_t flags) {
+  if (!c || !in_off || !out_off || !out_len || !status || !err_off || (n && (!in || !out)))
+    return FLATE_HIP_E_INVALID;
+  c->hip_err.clear();
+  if (n == 0) return FLATE_HIP_OK;
+  for (uint32_t i = 0; i < n; ++i)
+    if (in_off[i + 1] < in_off[i] || out_off[i + 1] < out_off[i]) return FLATE_HIP_E_INVALID;
+  for (uint32_t i = 0; i < n; ++i)
+    if (in_off[i + 1] - in_off[i] >= 0x7ffe0000ull) return FLATE_HIP_E_TOO_LARGE;
+  return inflate_common(c, in, in_off, n, out, out_off, out_len, status, err_off, flags, 0);
+}
+
+int flate_hip_inflate_spliced(flate_hip_ctx *c, const uint8_t *in, uint64_t in_len,
+                              const uint64_t *bit_off, uint32_t n, uint8_t *out,
+                              const uint64_t *out_off, uint64_t *out_len, int32_t *status,
+                              int64_t *err_off, uint32_t flags) {
+  if (!c || !in || !in_len || !bit_off || !out_off || !out_len || !status || !err_off || (n && !out))
+    return FLATE_HIP_E_INVALID;
+  c->hip_err.clear();
+  if (n == 0) return FLATE_HIP_OK;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (bit_off[i + 1] < bit_off[i] || out_off[i + 1] < out_off[i] || bit_off[i + 1] > in_len * 8)
+      return FLATE_HIP_E_INVALID;
+    if (bit_off[i + 1] - bit_off[i] >= (1ull << 30)) return FLATE_HIP_E_TOO_LARGE;  // piece < 128 MiB
+  }
+  return inflate_common(c, in, bit_off, n, out, out_off, out_len, status, err_off, flags, in_len);
 }
 
 }  // extern "C"

@@ -827,17 +827,36 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
   out_cap = 0;
   b.in = P.in;
   b.in_len = 0;
+  // spliced input: the lane's piece ends at this bit (relative to b.in); ~0 = runs to BFINAL
+  uint32_t stop_bit = ~0u;
+  uint64_t in_base = 0;  // byte offset of b.in inside P.in (for the reported error offset)
+  uint32_t start_bit = 0;
   if (have) {
     out = P.out + P.out_off[sid];
     const uint64_t cap64 = P.out_off[sid + 1] - P.out_off[sid];
     out_cap = cap64 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)cap64;
-    b.in = P.in + P.in_off[sid];
-    b.in_len = (uint32_t)(P.in_off[sid + 1] - P.in_off[sid]);  // < 2^28: checked by the host
+    if (P.bit_off == nullptr) {
+      b.in = P.in + P.in_off[sid];
+      b.in_len = (uint32_t)(P.in_off[sid + 1] - P.in_off[sid]);  // < 2^28: checked by the host
+    } else {
+      // bit positions are kept relative to the dword the piece starts in (32-bit arithmetic; byte
+      // alignment relative to the whole stream is preserved, as stored blocks need it)
+      const uint64_t g0 = P.bit_off[sid], g1 = P.bit_off[sid + 1];
+      in_base = (g0 >> 5) * 4;
+      b.in = P.in + in_base;
+      start_bit = (uint32_t)(g0 - 8 * in_base);
+      const uint64_t rest = P.in_len - in_base;
+      b.in_len = rest < (1ull << 28) ? (uint32_t)rest : (1u << 28);
+      if (sid + 1 != P.n_streams) stop_bit = (uint32_t)(g1 - 8 * in_base);  // piece < 2^28 B: host
+    }
   }
   b.in_bits = b.in_len * 8u;
   b.bitpos = b.hi = b.widx = 0;
   b.w0 = b.w1 = b.w2 = b.n0 = b.n1 = 0;
-  if (have) sb_start(b, 0);
+  if (have) {
+    sb_start(b, 0);
+    b.bitpos = b.hi = start_bit;  // < 32: still inside the window's first dword
+  }
   opos = 0;
   state = have ? S_BLOCK : S_DONE;
   err = 0;
@@ -906,6 +925,10 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
       sb_sync(b);
       if (final_block) {
         state = S_DONE;
+        if (stop_bit != ~0u) serr = E_CORRUPT;  // BFINAL inside a spliced stream
+      } else if (b.bitpos >= stop_bit) {        // spliced input: the next piece starts here
+        state = S_DONE;
+        if (b.bitpos != stop_bit) serr = E_CORRUPT;  // the index does not point at a block boundary
       } else if (!sb_need(b, 3)) {
         serr = E_EOF;
       } else {
@@ -1195,7 +1218,7 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
   if (have) {
     P.out_len[sid] = opos;
     P.status[sid] = err;
-    P.err_off[sid] = err == E_CORRUPT ? (long long)sb_roffset(b) : -1;
+    P.err_off[sid] = err == E_CORRUPT ? (long long)(in_base + sb_roffset(b)) : -1;
   }
 }
 template __global__ void inflate_simt_kernel<64>(InfParams);

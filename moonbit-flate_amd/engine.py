@@ -197,6 +197,37 @@ class FlateEngine:
             bit_off.ctypes.data, self._flags(compat_go, False, device)))
         return out, int(out_len.value), bit_off
 
+    def inflate_spliced(self, data, nbytes, bit_off, out_sizes, out=None, check=True):
+        """Decompress ONE spliced DEFLATE stream data[:nbytes] in parallel from its index:
+        piece i starts at bit bit_off[i].  Returns (out, out_off, out_len, status, err_off)."""
+        bit_off = np.ascontiguousarray(bit_off, dtype=np.uint64)
+        n = bit_off.size - 1
+        out_off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(np.asarray(out_sizes, dtype=np.uint64), out=out_off[1:])
+        out_len = np.zeros(max(n, 1), dtype=np.uint64)
+        status = np.zeros(max(n, 1), dtype=np.int32)
+        err_off = np.full(max(n, 1), -1, dtype=np.int64)
+        device = _is_torch(data)
+        total = max(int(out_off[-1]), 16)
+        if device:
+            import torch
+            assert data.dtype == torch.uint8 and data.is_cuda and data.is_contiguous()
+            if out is None:
+                out = torch.empty(total, dtype=torch.uint8, device=data.device)
+            in_ptr, out_ptr = data.data_ptr(), out.data_ptr()
+        else:
+            data = np.ascontiguousarray(data, dtype=np.uint8)
+            if out is None:
+                out = np.zeros(total, dtype=np.uint8)
+            in_ptr, out_ptr = data.ctypes.data, out.ctypes.data
+        rc = self._L.flate_hip_inflate_spliced(self._ctx, in_ptr, int(nbytes), bit_off.ctypes.data, n,
+                                               out_ptr, out_off.ctypes.data, out_len.ctypes.data,
+                                               status.ctypes.data, err_off.ctypes.data,
+                                               DEVICE_PTRS if device else 0)
+        if rc != 0 and (check or rc not in (E_OUT_TOO_SMALL, E_CORRUPT, E_UNEXPECTED_EOF)):
+            self._check(rc)
+        return out, out_off, out_len[:n], status[:n], err_off[:n]
+
     def lz77_matches(self, data, in_off, compat_go=False, lz_serial=False):
         """Match finder only.  Returns a list over LZ77 chunks (stream order) of
         (pos uint32[], tok uint32[]) and the per-stream chunk counts."""

@@ -144,3 +144,36 @@ def test_gpu_spliced_full_size_config2(eng):
         p = int(bit_off[i]) // 8
         assert torch.equal(out[p:p + (b - a)], comp[a:b])
     assert bytes(out[nbytes - 5:nbytes].cpu().numpy()) == b"\x01\x00\x00\xff\xff"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("compat", ["moonbit", "go"])
+def test_gpu_inflate_spliced_from_the_index(eng, oracle, compat):
+    """One spliced stream decoded in parallel from bit_off == what a single Reader over the whole
+    stream produces (the oracle's inflater), piece by piece."""
+    data, off = make_streams(SPECS * 3, seed=13)
+    go = compat == "go"
+    spliced, bit_off = oracle.deflate_spliced(data, off, oracle.COMPAT_GO if go else oracle.COMPAT_MOONBIT)
+    sizes = [int(off[i + 1] - off[i]) for i in range(len(off) - 1)]
+    comp = np.frombuffer(spliced + b"\0" * 8, dtype=np.uint8).copy()
+    out, ooff, olen, status, _ = eng.inflate_spliced(comp, len(spliced), bit_off, sizes)
+    assert (status == 0).all() and list(olen) == sizes
+    whole = oracle.inflate(spliced, int(off[-1]))
+    assert bytes(out[:int(off[-1])]) == whole == data[:int(off[-1])].tobytes()
+
+
+@pytest.mark.gpu
+def test_gpu_inflate_spliced_bad_index_and_full_round_trip(eng, oracle):
+    import torch
+    n, blen = 4096, 65536
+    host = flate.synth("text", n, blen, seed=0x5EED0001)
+    d_in = torch.from_numpy(host).cuda()
+    in_off = flate.uniform_offsets(n, blen)
+    comp, nbytes, bit_off = eng.deflate_spliced(d_in, in_off)
+    out, _, olen, status, _ = eng.inflate_spliced(comp, nbytes, bit_off, [blen] * n)
+    assert (status == 0).all() and (olen == blen).all() and torch.equal(out[:n * blen], d_in)
+    bad = bit_off.copy()
+    bad[7] += 1          # piece 6 now runs into piece 7's first block, piece 7 starts mid-block
+    _, _, _, status, _ = eng.inflate_spliced(comp, nbytes, bad, [blen] * n, check=False)
+    assert status[6] in (-2, -4) and status[7] != 0   # output overflow or off-boundary stop
+    assert (np.delete(status, [6, 7]) == 0).all()
