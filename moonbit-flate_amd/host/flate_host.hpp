@@ -3,12 +3,15 @@
 //   Writer::new / write / close          writer.mbt:10,45,53
 //   Compressor sticky errors             deflate.mbt:74,154-183,280-294
 //   writer_closed_error                  deflate.mbt:154
+//   &Reader::new / read / close, ioeof    inflate.mbt:305,382,410,19
+//   corrupt_input_error                   inflate.mbt:38
 // The reference is single-stream and synchronous; the GPU engine is a batch engine, so Writer
 // buffers write() calls (the 65535-byte staging window of deflate.mbt:222-229 makes the output a
 // function of the concatenated bytes only) and compresses in close().  BatchWriter closes many
 // streams with one kernel pipeline -- the intended way to use the engine.
 #pragma once
 
+#include <algorithm>
 #include <cstdint>
 #include <optional>
 #include <string>
@@ -128,5 +131,186 @@ class Writer {
   std::vector<uint8_t> pending_;
   Err err_;
 };
+
+// ---- spliced form (no reference counterpart): one DEFLATE stream for the batch ----
+inline Err compress_spliced(Engine &e, const std::vector<std::vector<uint8_t>> &streams,
+                            std::vector<uint8_t> &out, std::vector<uint64_t> *bit_off = nullptr,
+                            uint32_t flags = 0) {
+  if (!e.ok()) return make_error(e, e.status());
+  const uint32_t n = (uint32_t)streams.size();
+  std::vector<uint64_t> in_off(n + 1, 0), bo(n + 1, 0);
+  uint64_t cap = 16;
+  for (uint32_t i = 0; i < n; ++i) {
+    in_off[i + 1] = in_off[i] + streams[i].size();
+    cap += flate_hip_deflate_bound(streams[i].size());
+  }
+  std::vector<uint8_t> in(in_off[n] + 1), buf(cap);
+  for (uint32_t i = 0; i < n; ++i)
+    std::copy(streams[i].begin(), streams[i].end(), in.begin() + in_off[i]);
+  uint64_t len = 0;
+  const int rc = flate_hip_deflate_fast_spliced(e.ctx(), in.data(), in_off.data(), n, buf.data(), cap, &len,
+                                                bo.data(), flags);
+  if (rc != 0) return make_error(e, rc);
+  out.assign(buf.begin(), buf.begin() + len);
+  if (bit_off) *bit_off = bo;
+  return std::nullopt;
+}
+
+// ---- decode side ---------------------------------------------------------------------------
+// pub let ioeof (inflate.mbt:19) and the errors of the Decompressor (inflate.mbt:38,780-785)
+inline const IOError &ioeof() {
+  static const IOError e{"EOF"};
+  return e;
+}
+inline IOError corrupt_input_error(long long off) {  // inflate.mbt:38-40
+  return IOError{"flate: corrupt input before offset " + std::to_string(off)};
+}
+inline const IOError &err_unexpected_eof() {  // @io.err_unexpected_eof via no_eof, inflate.mbt:780-785
+  static const IOError e{"unexpected EOF"};
+  return e;
+}
+
+struct Inflated {
+  std::vector<uint8_t> bytes;  // what was decoded (also in front of an error, as read() flushes it)
+  Err err;                     // nullopt, corrupt_input_error(offset) or err_unexpected_eof
+};
+
+// Decode independent streams in one batch.  sizes[i] = capacity for stream i's output.
+inline Err decompress_batch(Engine &e, const std::vector<std::vector<uint8_t>> &streams,
+                            const std::vector<uint64_t> &sizes, std::vector<Inflated> &out) {
+  if (!e.ok()) return make_error(e, e.status());
+  const uint32_t n = (uint32_t)streams.size();
+  std::vector<uint64_t> in_off(n + 1, 0), out_off(n + 1, 0), out_len(n + 1, 0);
+  std::vector<int32_t> status(n + 1, 0);
+  std::vector<int64_t> err_off(n + 1, -1);
+  for (uint32_t i = 0; i < n; ++i) {
+    in_off[i + 1] = in_off[i] + streams[i].size();
+    out_off[i + 1] = out_off[i] + sizes[i];
+  }
+  std::vector<uint8_t> in(in_off[n] + 8), buf(out_off[n] + 8);
+  for (uint32_t i = 0; i < n; ++i)
+    std::copy(streams[i].begin(), streams[i].end(), in.begin() + in_off[i]);
+  const int rc = flate_hip_inflate_batch(e.ctx(), in.data(), in_off.data(), n, buf.data(), out_off.data(),
+                                         out_len.data(), status.data(), err_off.data(), 0);
+  if (rc != 0 && rc != FLATE_HIP_E_CORRUPT && rc != FLATE_HIP_E_UNEXPECTED_EOF && rc != FLATE_HIP_E_OUT_TOO_SMALL)
+    return make_error(e, rc);
+  out.resize(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    out[i].bytes.assign(buf.begin() + out_off[i], buf.begin() + out_off[i] + out_len[i]);
+    out[i].err = std::nullopt;
+    if (status[i] == FLATE_HIP_E_CORRUPT) out[i].err = corrupt_input_error(err_off[i]);
+    else if (status[i] == FLATE_HIP_E_UNEXPECTED_EOF) out[i].err = err_unexpected_eof();
+    else if (status[i] != 0) out[i].err = make_error(e, status[i]);
+  }
+  return std::nullopt;
+}
+
+// &Reader (inflate.mbt:227-232): where a Decompressor pulls its input from
+struct ByteSource {
+  virtual ~ByteSource() = default;
+  virtual std::pair<int, Err> read(uint8_t *p, size_t n) = 0;  // (0, ioeof) at the end
+};
+struct BytesReader : ByteSource {  // @io.Buffer used as source
+  std::vector<uint8_t> bytes;
+  size_t pos = 0;
+  explicit BytesReader(std::vector<uint8_t> b) : bytes(std::move(b)) {}
+  std::pair<int, Err> read(uint8_t *p, size_t n) override {
+    if (pos == bytes.size()) return {0, ioeof()};
+    const size_t k = std::min(n, bytes.size() - pos);
+    std::copy(bytes.begin() + pos, bytes.begin() + pos + k, p);
+    pos += k;
+    return {(int)k, std::nullopt};
+  }
+};
+
+// &Reader::new(r) -> Decompressor (inflate.mbt:305) with read (:382-405) and close (:410-415).
+// The engine is a batch engine: the first read() pulls the whole source and decodes it; the
+// bytes and errors then come out as the reference hands them out -- data first, the error
+// (ioeof at a clean end) together with the last bytes, nothing but the error afterwards.
+class Reader {
+ public:
+  Reader(ByteSource &r, Engine &e, uint64_t size_hint = 0) : r_(r), e_(e), hint_(size_hint) {}
+
+  std::pair<int, Err> read(uint8_t *p, size_t n) {
+    if (!decoded_) decode();
+    if (pos_ < data_.size()) {
+      const size_t k = std::min(n, data_.size() - pos_);
+      std::copy(data_.begin() + pos_, data_.begin() + pos_ + k, p);
+      pos_ += k;
+      if (pos_ == data_.size()) return {(int)k, err_};  // :392-394
+      return {(int)k, std::nullopt};
+    }
+    return {0, err_};  // :397-400
+  }
+  Err close() {  // :410-415
+    if (err_ && *err_ == ioeof()) return std::nullopt;
+    return err_;
+  }
+
+ private:
+  void decode() {
+    decoded_ = true;
+    std::vector<uint8_t> src;
+    uint8_t tmp[4096];
+    for (;;) {
+      auto r = r_.read(tmp, sizeof tmp);
+      src.insert(src.end(), tmp, tmp + r.first);
+      if (r.second) {
+        if (!(*r.second == ioeof())) {
+          err_ = r.second;
+          return;
+        }
+        break;
+      }
+    }
+    uint64_t cap = hint_ ? hint_ : std::max<uint64_t>(4096, 8 * src.size());
+    for (;;) {  // the output size is not known in advance: grow the slot until it fits
+      std::vector<Inflated> out;
+      Err er = decompress_batch(e_, {src}, {cap}, out);
+      if (er) {
+        err_ = er;
+        return;
+      }
+      const bool small = out[0].err && out[0].err->msg.find("too small") != std::string::npos;
+      if (small && cap < (1ull << 31)) {
+        cap *= 4;
+        continue;
+      }
+      data_ = std::move(out[0].bytes);
+      err_ = out[0].err ? out[0].err : Err(ioeof());
+      return;
+    }
+  }
+  ByteSource &r_;
+  Engine &e_;
+  uint64_t hint_;
+  bool decoded_ = false;
+  std::vector<uint8_t> data_;
+  size_t pos_ = 0;
+  Err err_;
+};
+
+// One spliced stream decoded in parallel from its index (flate_hip_inflate_spliced).
+inline Err decompress_spliced(Engine &e, const std::vector<uint8_t> &stream, const std::vector<uint64_t> &bit_off,
+                              const std::vector<uint64_t> &sizes, std::vector<uint8_t> &out) {
+  if (!e.ok()) return make_error(e, e.status());
+  const uint32_t n = (uint32_t)sizes.size();
+  std::vector<uint64_t> out_off(n + 1, 0), out_len(n + 1, 0);
+  std::vector<int32_t> status(n + 1, 0);
+  std::vector<int64_t> err_off(n + 1, -1);
+  for (uint32_t i = 0; i < n; ++i) out_off[i + 1] = out_off[i] + sizes[i];
+  std::vector<uint8_t> in(stream);
+  in.resize(in.size() + 8);
+  out.assign(out_off[n] + 8, 0);
+  const int rc = flate_hip_inflate_spliced(e.ctx(), in.data(), stream.size(), bit_off.data(), n, out.data(),
+                                           out_off.data(), out_len.data(), status.data(), err_off.data(), 0);
+  if (rc != 0) {
+    for (uint32_t i = 0; i < n; ++i)
+      if (status[i] == FLATE_HIP_E_CORRUPT) return corrupt_input_error(err_off[i]);
+    return make_error(e, rc);
+  }
+  out.resize(out_off[n]);
+  return std::nullopt;
+}
 
 }  // namespace flate_host

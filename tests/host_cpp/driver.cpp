@@ -41,5 +41,55 @@ int main() {
   printf("batch %s\n", be ? be->msg.c_str() : "none");
   if (!be)
     for (size_t i = 0; i < out.size(); ++i) hex("stream", out[i]);
+
+  // &Reader::new + read in 7-byte pieces + close (inflate.mbt:305,382-405,410-415)
+  {
+    BytesReader src(b.bytes);
+    Reader r(src, eng);
+    uint8_t piece[7];
+    std::vector<uint8_t> got;
+    for (int k = 0; k < 7; ++k) {
+      auto rr = r.read(piece, sizeof piece);
+      got.insert(got.end(), piece, piece + rr.first);
+      printf("read %d %s\n", rr.first, rr.second ? rr.second->msg.c_str() : "none");
+    }
+    Err ce = r.close();
+    printf("rclose %s\n", ce ? ce->msg.c_str() : "none");
+    hex("plain", got);
+  }
+  // a corrupt stream: reserved block type in the first header (bits 1,1,1)
+  {
+    std::vector<uint8_t> bad = b.bytes;
+    bad[0] = 0x07;
+    BytesReader src(bad);
+    Reader r(src, eng);
+    uint8_t piece[64];
+    auto rr = r.read(piece, sizeof piece);
+    printf("badread %d %s\n", rr.first, rr.second ? rr.second->msg.c_str() : "none");
+    Err ce = r.close();
+    printf("badclose %s\n", ce ? ce->msg.c_str() : "none");
+  }
+  // truncated: unexpected EOF after the decodable part has been handed out
+  {
+    std::vector<uint8_t> cut(out[1].begin(), out[1].end() - 9);
+    BytesReader src(cut);
+    Reader r(src, eng, 70000);
+    std::vector<uint8_t> piece(70000);
+    auto rr = r.read(piece.data(), piece.size());
+    printf("cutread %d %s\n", rr.first, rr.second ? rr.second->msg.c_str() : "none");
+  }
+  // spliced pair: the same three streams as ONE DEFLATE stream and back
+  {
+    std::vector<uint8_t> one;
+    std::vector<uint64_t> bit_off;
+    Err se = compress_spliced(eng, in, one, &bit_off);
+    printf("spliced %s\n", se ? se->msg.c_str() : "none");
+    hex("one", one);
+    std::vector<uint8_t> back;
+    Err de = decompress_spliced(eng, one, bit_off, {0, 65536, 100}, back);
+    size_t diff = 0;
+    for (size_t i = 0; i < back.size(); ++i) diff += back[i] != (i < 65536 ? in[1][i] : in[2][i - 65536]);
+    printf("unspliced %s %zu %zu\n", de ? de->msg.c_str() : "none", back.size(), diff);
+  }
   return 0;
 }

@@ -34,11 +34,13 @@ def test_host_mirror_matches_reference_behaviour(oracle):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     lines = dict()
-    streams = []
+    streams, reads = [], []
     for ln in out.stdout.splitlines():
         k, _, v = ln.partition(" ")
         if k == "stream":
             streams.append(bytes.fromhex(v))
+        elif k == "read":
+            reads.append(v)
         else:
             lines[k] = v
     assert lines["write"] == "11 17"
@@ -52,3 +54,19 @@ def test_host_mirror_matches_reference_behaviour(oracle):
     assert streams[0] == oracle.deflate(b"") == bytes([1, 0, 0, 0xFF, 0xFF])
     assert streams[1] == oracle.deflate(ramp)
     assert streams[2] == oracle.deflate(bytes(100))
+    # Decompressor::read hands out data first and the error with the last bytes (inflate.mbt:382-405)
+    assert reads == ["7 none", "7 none", "7 none", "7 EOF", "0 EOF", "0 EOF", "0 EOF"]
+    assert lines["rclose"] == "none"                                    # :410-415
+    assert bytes.fromhex(lines["plain"]) == b"hello worldhello again world"
+    rc, _, _, err_off = oracle.inflate(bytes([7]) + want[1:], 100, full=True)
+    assert rc == oracle.E_CORRUPT
+    assert lines["badread"] == "0 flate: corrupt input before offset %d" % err_off   # :38-40
+    assert lines["badclose"] == "flate: corrupt input before offset %d" % err_off
+    rc, part, _, _ = oracle.inflate(oracle.deflate(ramp)[:-9], 70000, full=True)
+    assert rc == oracle.E_UNEXPECTED_EOF
+    assert lines["cutread"] == "%d unexpected EOF" % len(part)
+    assert lines["spliced"] == "none"
+    data = np.concatenate([ramp, np.zeros(100, np.uint8)])
+    ref, _ = oracle.deflate_spliced(data, np.array([0, 0, 65536, 65636], np.uint64))
+    assert bytes.fromhex(lines["one"]) == ref
+    assert lines["unspliced"] == "none 65636 0"
