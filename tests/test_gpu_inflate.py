@@ -110,3 +110,37 @@ def test_inflate_device_pointers_full_size(eng, oracle):
     out, ooff, olen, status, err = eng.inflate_batch(comp, coff, [65536] * n)
     assert (status == 0).all() and (olen == 65536).all()
     assert torch.equal(out[:n * 65536], d)
+
+
+def test_inflate_fuzz_foreign_block_mixes(eng, oracle):
+    """Streams from zlib at several levels/strategies (stored, fixed and dynamic blocks mixed, long
+    matches at distance 1, sync-flush stored blocks in the middle), sizes from 0 to 300 KB."""
+    rng = np.random.default_rng(1234)
+    blobs, plains = [], []
+    for k in range(160):
+        n = int(rng.choice([0, 1, 2, 5, 17, 100, 1000, 5000, 40000, 70000, 300000]))
+        kind = k % 5
+        if kind == 0:
+            raw = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        elif kind == 1:
+            raw = bytes(n)
+        elif kind == 2:
+            raw = (rng.integers(0, 4, n, dtype=np.uint8) + 97).tobytes()
+        elif kind == 3:
+            raw = (b"the quick brown fox jumps over the lazy dog " * (n // 44 + 1))[:n]
+        else:
+            raw = rng.integers(0, 256, max(n // 50, 1), dtype=np.uint8).tobytes() * 50
+            raw = raw[:n]
+        level = int(rng.choice([0, 1, 6, 9]))
+        strategy = int(rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE]))
+        c = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+        half = len(raw) // 2
+        blob = c.compress(raw[:half]) + c.flush(zlib.Z_SYNC_FLUSH) + c.compress(raw[half:]) + c.flush()
+        blobs.append(blob)
+        plains.append(raw)
+    data, off = _pack(blobs)
+    sizes = [len(p) for p in plains]
+    out, ooff, olen, status, _ = eng.inflate_batch(data, off, sizes)
+    assert (status == 0).all() and list(olen) == sizes
+    for i, p in enumerate(plains):
+        assert bytes(out[int(ooff[i]):int(ooff[i]) + len(p)]) == p, i

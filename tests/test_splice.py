@@ -177,3 +177,23 @@ def test_gpu_inflate_spliced_bad_index_and_full_round_trip(eng, oracle):
     _, _, _, status, _ = eng.inflate_spliced(comp, nbytes, bad, [blen] * n, check=False)
     assert status[6] in (-2, -4) and status[7] != 0   # output overflow or off-boundary stop
     assert (np.delete(status, [6, 7]) == 0).all()
+
+
+@pytest.mark.gpu
+def test_gpu_spliced_fuzz_random_sizes(eng, oracle):
+    rng = np.random.default_rng(77)
+    kinds = ["text", "ramp", "zero", "rand", "low", "period", "runs"]
+    for rnd in range(4):
+        specs = [(kinds[int(rng.integers(len(kinds)))],
+                  int(rng.choice([0, 1, 3, 15, 16, 17, 18, 100, 127, 128, 129, 2000, 65534, 65535, 65536,
+                                  65537, 65551, 65552, 70000, 131070, 131071, 140000])))
+                 for _ in range(60)]
+        data, off = make_streams(specs, seed=100 + rnd)
+        go = bool(rnd & 1)
+        out, n, bit_off = eng.deflate_spliced(data, off, compat_go=go)
+        ref, ref_off = oracle.deflate_spliced(data, off, oracle.COMPAT_GO if go else oracle.COMPAT_MOONBIT)
+        assert bytes(out[:n]) == ref and np.array_equal(bit_off, ref_off), rnd
+        sizes = [s for _, s in specs]
+        back, _, olen, status, _ = eng.inflate_spliced(out, n, bit_off, sizes)
+        assert (status == 0).all() and list(olen) == sizes
+        assert bytes(back[:int(off[-1])]) == data[:int(off[-1])].tobytes()
