@@ -57,7 +57,8 @@ def main():
     ap.add_argument("--kind", default="text", choices=["text", "ramp", "rand", "zero"])
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather (N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-streams", type=int, default=4096)
+    ap.add_argument("--cpu-sample-streams", type=int, default=16384,
+                    help="streams of the workload the CPU oracle is timed on (about 10 CPU-seconds per GiB)")
     ap.add_argument("--verify", type=int, default=64, help="streams checked against the oracle")
     ap.add_argument("--no-guests", action="store_true",
                     help="match finder with LDS-table blocks only (no L2-table guest blocks); the "
@@ -252,7 +253,7 @@ def bench_inflate(args, flate, eng, d_in, in_off, n, blen, world, rank, dev, dis
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.spliced:
         import numpy as np
         from oracle import pyoracle
-        ns = min(args.cpu_sample_streams * 4, n)  # the decoder is several times faster than the encoder
+        ns = min(args.cpu_sample_streams * 2, n)  # the decoder is faster than the encoder
         cores = min(os.cpu_count() or 1, 16)
         h_off = np.asarray(coff[:ns + 1], dtype=np.uint64)
         h_comp = comp[:int(h_off[-1])].cpu().numpy()
