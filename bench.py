@@ -110,22 +110,40 @@ def main():
 
     gather = (world > 1) and not args.no_gather
     shard = importlib.import_module("moonbit-flate_amd.shard")
-    gathered = None
+    # The exchange step of batch k (all-gather over xGMI) overlaps the compression of batch k+1:
+    # two output buffers alternate, a buffer is reused only after the gather that reads it is done,
+    # and every gather completes inside the timed region (sync_all waits for all streams).
+    outs = [out, torch.empty_like(out)] if gather else [out]
+    pending = [None] * len(outs)
+    gbuf = None
+    nstep = 0
 
     def step():
-        nonlocal gathered
+        nonlocal gbuf, nstep
+        i = nstep % len(outs)
+        nstep += 1
+        if pending[i] is not None:
+            pending[i].wait()
+            pending[i] = None
         if args.spliced:  # one DEFLATE stream per GPU; the gather then moves one "stream" per rank
             import numpy as np
-            _, nbytes, _ = eng.deflate_spliced(d_in, in_off, out=out)
+            _, nbytes, _ = eng.deflate_spliced(d_in, in_off, out=outs[i])
             out_off = np.array([0, nbytes], dtype=np.uint64)
         else:
-            _, out_off = eng.deflate_batch(d_in, in_off, out=out)
+            _, out_off = eng.deflate_batch(d_in, in_off, out=outs[i])
         if gather:  # north_star's exchange step: every rank ends up with every compressed shard
-            gathered = shard.gather_compressed(dist, out, out_off,
-                                               buf=None if gathered is None else gathered.buf)
+            pending[i] = shard.gather_compressed(dist, outs[i], out_off, buf=gbuf, wait=False)
+            gbuf = pending[i].buf
         return out_off
 
+    def drain():
+        for j, g in enumerate(pending):
+            if g is not None:
+                g.wait()
+                pending[j] = None
+
     def sync_all():
+        drain()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -197,7 +215,7 @@ def main():
                                ", spliced into ONE stream per GPU" if args.spliced else ""),
                 "streams_per_gpu": n, "stream_len": blen, "kind": args.kind,
                 "compressed_bytes_per_gpu": clen, "ratio": round(ratio, 4),
-                "gather": "rccl all_gather_into_tensor (padded)" if gather else "none",
+                "gather": "rccl all_gather_into_tensor (padded), overlapped with the next batch" if gather else "none",
                 "parity_checked_streams": verified,
                 "stage_ms": {k: round(v / steps, 3) for k, v in stage_ms.items()},
             },

@@ -14,17 +14,28 @@ class GatheredStreams:
     """All ranks' compressed streams on this rank: rank r's payload sits at buf[r*pad : r*pad+size[r]],
     global stream j (rank-major order) at buf[off[j] : off[j] + length[j]]."""
 
-    def __init__(self, buf, pad, sizes, counts, off, length):
+    def __init__(self, buf, pad, sizes, counts, off, length, work=None):
         self.buf, self.pad, self.sizes, self.counts, self.off, self.length = \
             buf, pad, sizes, counts, off, length
+        self.work = work  # pending payload collective (gather_compressed(..., wait=False)) or None
+
+    def wait(self):
+        """Make the current stream (and for gloo the host) wait for the payload; idempotent."""
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        return self
 
     def stream(self, j):
         o = int(self.off[j])
         return self.buf[o:o + int(self.length[j])]
 
 
-def gather_compressed(dist, local_buf, local_off, buf=None, pad_to=1 << 20):
+def gather_compressed(dist, local_buf, local_off, buf=None, pad_to=1 << 20, wait=True):
     """Concatenate every rank's compressed shard on every rank.
+
+    wait=False leaves the payload all-gather in flight (call .wait() on the result before reading
+    buf or overwriting local_buf): the next batch can then be compressed while xGMI moves this one.
 
     local_buf: torch uint8 tensor holding this rank's streams back to back (may be larger than the
     payload); local_off: numpy uint64[k+1] offsets.  Uses two all-gathers: the (size, count, index)
@@ -55,10 +66,13 @@ def gather_compressed(dist, local_buf, local_off, buf=None, pad_to=1 << 20):
         local_buf = grown
     if buf is None or buf.numel() < pad * world:
         buf = torch.empty(pad * world, dtype=torch.uint8, device=dev)
-    dist.all_gather_into_tensor(buf[:pad * world], local_buf[:pad])
+    work = dist.all_gather_into_tensor(buf[:pad * world], local_buf[:pad], async_op=True)
+    if wait:
+        work.wait()
+        work = None
     off, length = [], []
     for r in range(world):
         o = idxs[r, :counts[r] + 1].astype(np.uint64)
         off.append(o[:-1] + np.uint64(r * pad))
         length.append(o[1:] - o[:-1])
-    return GatheredStreams(buf, pad, sizes, counts, np.concatenate(off), np.concatenate(length))
+    return GatheredStreams(buf, pad, sizes, counts, np.concatenate(off), np.concatenate(length), work)

@@ -39,7 +39,14 @@ def _worker(rank, world, port, n_streams, q):
     np.cumsum([c.size for c in comp], out=off[1:])
     local = torch.from_numpy(np.concatenate(comp).copy())
     g = shard.gather_compressed(dist, local, off, pad_to=4096)
-    ok = True
+    # the overlapped form used by bench.py: two gathers in flight into the same destination, each
+    # from its own source buffer; the result of the later one is what remains
+    decoy = torch.zeros_like(local)
+    g0 = shard.gather_compressed(dist, decoy, off, pad_to=4096, wait=False)
+    g1 = shard.gather_compressed(dist, local.clone(), off, buf=g0.buf, pad_to=4096, wait=False)
+    g0.wait()
+    g1.wait().wait()
+    ok = torch.equal(g1.buf[:g.pad * world], g.buf[:g.pad * world])
     # every rank must now hold every stream, in global order, bit-exact
     for j in range(n_streams):
         want = pyoracle.deflate(flate.synth("text", 1, lens[j], first_stream=j))
