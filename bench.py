@@ -52,7 +52,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--streams", type=int, default=16384, help="streams per GPU")
+    ap.add_argument("--streams", type=int, default=None,
+                    help="streams per GPU (default: 16384 = 1 GiB, configs[1]; --mode inflate: 131072 = 8 GiB, configs[4])")
     ap.add_argument("--stream-len", type=int, default=65536)
     ap.add_argument("--kind", default="text", choices=["text", "ramp", "rand", "zero"])
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather (N>1)")
@@ -70,6 +71,8 @@ def main():
     ap.add_argument("--mode", default="deflate", choices=["deflate", "inflate"],
                     help="inflate = BASELINE.json configs[4]: decode the compressed streams (stream index supplied)")
     args = ap.parse_args()
+    if args.streams is None:
+        args.streams = 131072 if args.mode == "inflate" else 16384
 
     import torch
     flate = importlib.import_module("moonbit-flate_amd")
