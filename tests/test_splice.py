@@ -197,3 +197,19 @@ def test_gpu_spliced_fuzz_random_sizes(eng, oracle):
         back, _, olen, status, _ = eng.inflate_spliced(out, n, bit_off, sizes)
         assert (status == 0).all() and list(olen) == sizes
         assert bytes(back[:int(off[-1])]) == data[:int(off[-1])].tobytes()
+
+
+@pytest.mark.gpu
+def test_config5_full_size_round_trip(eng):
+    """BASELINE configs[4] at full size: 131072 x 64 KiB (8 GiB) -> ONE compressed stream ->
+    decoded in parallel from its index == the input (encode -> decode round-trip property)."""
+    import torch
+    n, blen = 131072, 65536
+    d_in = torch.from_numpy(flate.synth("text", n, blen, seed=0x5EED0001)).cuda()
+    in_off = flate.uniform_offsets(n, blen)
+    comp, nbytes, bit_off = eng.deflate_spliced(d_in, in_off)
+    assert 3.0e9 < nbytes < 4.5e9 and int(bit_off[-1]) // 8 + 5 == nbytes
+    comp = comp[:nbytes + 8].clone()          # drop the bound-sized buffer before the 8 GiB output
+    out, _, olen, status, _ = eng.inflate_spliced(comp, nbytes, bit_off, [blen] * n)
+    assert (status == 0).all() and (olen == blen).all()
+    assert torch.equal(out[:n * blen], d_in)
