@@ -1,0 +1,28 @@
+/*
+ * flate_hip_stub.c -- the few lines of C the MoonBit native backend needs next to
+ * libflate_hip.so.  MoonBit's `extern "C"` cannot take
+ * a pointer-to-pointer, so the context constructor is wrapped; everything else binds
+ * include/flate_hip.h directly.  UNVERIFIED with moon (not available in the build image); this file
+ * itself is compiled by tests/test_library_abi.py to keep it in step with the header.
+ */
+#include "flate_hip.h"
+
+/* -> flate_hip_ctx* or NULL; *rc_out (optional) receives the error code */
+flate_hip_ctx *flate_hip_mbt_ctx_new(int device) {
+  flate_hip_ctx *c = 0;
+  if (flate_hip_init(device, &c) != FLATE_HIP_OK) return 0;
+  return c;
+}
+
+/* MoonBit Int64/UInt64 FixedArrays are passed as plain pointers: these two calls only fix the
+ * argument order and types the .mbt file declares. */
+int flate_hip_mbt_deflate_batch(flate_hip_ctx *c, const uint8_t *in, const uint64_t *in_off, uint32_t n,
+                                uint8_t *out, uint64_t out_cap, uint64_t *out_off, uint32_t flags) {
+  return flate_hip_deflate_fast_batch(c, in, in_off, n, out, out_cap, out_off, flags);
+}
+
+int flate_hip_mbt_inflate_batch(flate_hip_ctx *c, const uint8_t *in, const uint64_t *in_off, uint32_t n,
+                                uint8_t *out, const uint64_t *out_off, uint64_t *out_len, int32_t *status,
+                                int64_t *err_off, uint32_t flags) {
+  return flate_hip_inflate_batch(c, in, in_off, n, out, out_off, out_len, status, err_off, flags);
+}

@@ -80,3 +80,21 @@ def test_tokens_from_matches_roundtrip(oracle):
             p += 1
     got = flate.tokens_from_matches(data, np.array(pos, np.uint32), np.array(tok, np.uint32))
     assert np.array_equal(got, toks)
+
+
+def test_moonbit_stub_compiles_and_links_against_the_library(lib, tmp_path):
+    """integration/moonbit/flate_hip_stub.c (the C side of the MoonBit binding) stays in
+    step with include/flate_hip.h: it compiles warning-free and its symbols resolve against the .so."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = tmp_path / "libstub.so"
+    libdir = os.path.join(root, "moonbit-flate_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-shared", "-fPIC",
+                           "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "integration", "moonbit", "flate_hip_stub.c"),
+                           "-L" + libdir, "-lflate_hip", "-Wl,-rpath," + libdir, "-Wl,--no-undefined",
+                           "-o", str(so)])
+    import ctypes
+    stub = ctypes.CDLL(str(so))
+    for name in ("flate_hip_mbt_ctx_new", "flate_hip_mbt_deflate_batch", "flate_hip_mbt_inflate_batch"):
+        assert hasattr(stub, name)
