@@ -130,8 +130,7 @@ int flate_hip_inflate_spliced(flate_hip_ctx *ctx, const uint8_t *in, uint64_t in
  * All other blocks carry BFINAL=0 (deflate.mbt:251,267,269).  *out_len = bytes of the
  * stream; bit_off (host, n_streams+1 entries, may be NULL) = bit position of every
  * stream's first block (the stream index a parallel decoder needs).  out_cap must be
- * at least the result + 3 bytes (sum of flate_hip_deflate_bound is always enough); out
- * is zeroed up to out_cap. */
+ * at least the result + 3 bytes (sum of flate_hip_deflate_bound is always enough). */
 int flate_hip_deflate_fast_spliced(flate_hip_ctx *ctx, const uint8_t *in,
                                    const uint64_t *in_off, uint32_t n_streams, uint8_t *out,
                                    uint64_t out_cap, uint64_t *out_len, uint64_t *bit_off,

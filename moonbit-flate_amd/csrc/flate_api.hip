@@ -448,7 +448,6 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
   if ((rc = ensure(c, c->d_out_off, ((size_t)n + 1) * 8))) return rc;
   if (spliced) {
     if ((rc = ensure(c, c->d_slot_off, ((size_t)n + 1) * 16))) return rc;  // stream summaries {a, b}
-    HIP_TRY(c, hipMemsetAsync(d_out, 0, out_cap, c->stream));  // shared dwords are OR-ed in
   }
   HIP_TRY(c, hipMemcpyAsync(c->d_blk_base.p, pl.blk_base.data(), ((size_t)n + 1) * 4,
                             hipMemcpyHostToDevice, c->stream));
@@ -496,6 +495,7 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
       S.status = (int *)c->d_status.p;
       S.n_streams = n;
       hipLaunchKernelGGL(splice_scan_kernel, dim3(1), dim3(1024), 0, c->stream, S);
+      hipLaunchKernelGGL(splice_zero_kernel, dim3(n / 256 + 1), dim3(256), 0, c->stream, S, d_out);
     }
     hipLaunchKernelGGL(huff_pack_kernel, dim3(n), dim3(64), 0, c->stream, H);
   }

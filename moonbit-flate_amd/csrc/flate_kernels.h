@@ -101,6 +101,7 @@ struct SpliceParams {
   uint32_t n_streams;
 };
 __global__ void splice_scan_kernel(SpliceParams P);
+__global__ void splice_zero_kernel(SpliceParams P, uint8_t *out);
 size_t inflate_simt_lds_bytes(int lanes_per_wave);  // dynamic LDS of that launch
 
 }  // namespace flate

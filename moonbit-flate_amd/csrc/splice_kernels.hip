@@ -74,4 +74,29 @@ __global__ __launch_bounds__(1024) void splice_scan_kernel(SpliceParams P) {
   }
 }
 
+// The pack kernel ORs into the dwords a stream shares with its neighbours (its first and its last
+// one) and plainly stores all others, so only those need to be zero beforehand: the dword holding
+// bit stream_bit[i] and the one in front of it, for every i, plus the closing block's.
+__global__ __launch_bounds__(256) void splice_zero_kernel(SpliceParams P, uint8_t *out) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (i > P.n_streams || *P.status != 0) return;
+  const uint64_t mis = (uint64_t)(reinterpret_cast<uintptr_t>(out) & 3u);
+  uint32_t *dst = reinterpret_cast<uint32_t *>(out - mis);
+  const uint64_t g = P.stream_bit[i] + 8 * mis;
+  if ((g >> 5) == 0) {  // the grid's first dword starts mis bytes in front of out: not ours to write
+    for (uint64_t k = mis; k < 4; ++k) out[k - mis] = 0;
+  } else {
+    dst[g >> 5] = 0;
+    if ((g >> 5) == 1) {
+      for (uint64_t k = mis; k < 4; ++k) out[k - mis] = 0;
+    } else {
+      dst[(g >> 5) - 1] = 0;
+    }
+  }
+  if (i == P.n_streams) {  // closing block: 3 bits, padding, LEN, NLEN -- at most 3 more dwords
+    const uint64_t end = (*P.total_bytes + mis) * 8;
+    for (uint64_t d = (g >> 5) + 1; d * 32 < end; ++d) dst[d] = 0;
+  }
+}
+
 }  // namespace flate

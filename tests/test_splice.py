@@ -99,8 +99,10 @@ def test_gpu_spliced_device_pointers_and_relation_to_the_batch_output(eng, oracl
     d_in = torch.from_numpy(host).cuda()
     in_off = flate.uniform_offsets(n, blen)
     comp, coff = eng.deflate_batch(d_in, in_off)
-    dst = torch.empty(int(coff[-1]) + 64, dtype=torch.uint8, device="cuda")[3:]
+    whole = torch.full((int(coff[-1]) + 64,), 0xA5, dtype=torch.uint8, device="cuda")
+    dst = whole[3:]
     out, nbytes, bit_off = eng.deflate_spliced(d_in, in_off, out=dst)
+    assert whole[:3].tolist() == [0xA5] * 3        # nothing in front of the destination is touched
     assert not (bit_off % 8).any()
     assert nbytes == int(coff[-1]) - 5 * (n - 1)
     comp_h, res = comp.cpu().numpy(), out[:nbytes].cpu().numpy()
