@@ -47,6 +47,20 @@ def lz_traffic(args, n, blen):
     return None
 
 
+def inflate_traffic(args, n, blen):
+    """HBM bytes per launch of inflate_simt_kernel from the rocprofv3 --pmc passes kept in
+    profiles/r01/v10_inflate_pmc.json (measured on 65536 x 64 KiB S-text streams; the kernel does the
+    same work per stream at any batch size that fills the GPU, so the figure scales with n)."""
+    if not (args.kind == "text" and blen == 65536 and n >= 65536 and not args.spliced):
+        return None
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01", "v10_inflate_pmc.json")))
+        h = d["hbm_bytes_per_launch"]
+        return int((h["read_raw_FETCH_SIZE"] + h["written_WRITE_SIZE"]) * n / 65536)
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -304,7 +318,7 @@ def bench_inflate(args, flate, eng, d_in, in_off, n, blen, world, rank, dev, dis
             "roofline": {"bound": "hbm", "kernel": "inflate_simt_kernel" if n >= 2048 else "inflate_kernel",
                          "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": None},
+                         "traffic": inflate_traffic(args, n, blen)},
             "cpu_baseline": cpu_baseline}))
     if dist is not None:
         dist.barrier()
