@@ -57,7 +57,7 @@ void flate_hip_destroy(flate_hip_ctx *ctx);
 int flate_hip_set_stream(flate_hip_ctx *ctx, void *hip_stream);
 /* Tuning knobs of the match finder's launch geometry (results never change):
  *   "guest_blocks"       extra persistent wavefronts whose hash table lives in L2 instead of LDS
- *                        (default 4 per CU; 0 = off)
+ *                        (default 5 per CU; 0 = off)
  *   "resident_blocks"    persistent LDS-table wavefronts (default 5 per CU)
  *   "guest_min_streams"  batches smaller than this use one block per stream (default 4096)
  *   "inflate_simt_min_streams"  inflate batches at least this large decode one stream per LANE

@@ -321,14 +321,14 @@ int flate_hip_init(int device, flate_hip_ctx **out) {
     delete c;
     return FLATE_HIP_E_HIP;
   }
-  {  // 5 resident (LDS-table) + 4 guest (L2-table) match-finder waves per CU (measured best)
+  {  // 5 resident (LDS-table) + 5 guest (L2-table) match-finder waves per CU (measured best)
     hipDeviceProp_t prop;
     int cus = 256;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
       cus = prop.multiProcessorCount;
     c->num_cus = (uint32_t)cus;
     c->resident_blocks = 5u * (uint32_t)cus;
-    c->guest_blocks = 4 * cus;
+    c->guest_blocks = 5 * cus;
   }
   if (const char *e = getenv("FLATE_HIP_GUEST_BLOCKS")) c->guest_blocks = atoi(e);
   if (const char *e = getenv("FLATE_HIP_GUEST_SHARE")) c->guest_share = (float)atof(e);

@@ -247,7 +247,9 @@ FLATE_D int extend_match(const uint8_t *src, const uint8_t *stream, uint32_t W, 
 // because a sparse batch never spans more than kSpanMax positions.
 constexpr uint32_t kSweepEvery = 8192, kSpanMax = 16384, kMarkerBack = 36864;
 
-template <bool MULTI>
+// GUEST: the table is a slice of HBM scratch living in L2 (lz77_guest_kernel).  Same algorithm;
+// only the detection of lanes that share a slot avoids the table there (see the dense batch).
+template <bool MULTI, bool GUEST = false>
 FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table, const int lane) {
   using E = uint16_t;
   {
@@ -334,19 +336,36 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
           if (pq > n - 4) pq = n - 4;
           pf_val = ld32(src + pq);
         }
-        // duplicate-slot detection: speculative insert of all 64 positions + read-back
-        asm volatile("" ::: "memory");
-        if (e1) table[h] = (E)A1;
-        asm volatile("" ::: "memory");
-        const uint32_t rb = e1 ? (uint32_t)table[h] : (A1 & kEMask);
-        asm volatile("" ::: "memory");
-        const bool loser = rb != (A1 & kEMask);
-        const uint64_t LM = __ballot(loser);
         // DUPall: every lane that shares its slot with another lane of the batch (the commit
         // below must order their writes).  DUP: the lanes whose candidate may be a position
         // inserted by this batch, i.e. all but the first member of each group -- for the common
         // two-lane group only the later lane.
-        uint64_t DUPall = LM, DUP = 0;
+        uint64_t DUPall = 0, DUP = 0;
+        uint64_t eq = 0;  // GUEST: the lanes whose slot is mine (including me)
+        if (GUEST) {
+          // With the table in L2 a speculative insert + read-back costs two more memory round
+          // trips per batch; the lanes with equal hashes are found with one ballot per hash bit
+          // instead and the table is not touched before the commit.
+          eq = E1;
+#pragma unroll
+          for (int k = 0; k < kTableBits; ++k) {
+            const bool bit = (h >> k) & 1u;
+            const uint64_t m = __ballot(bit);
+            eq &= bit ? m : ~m;
+          }
+          if (!e1) eq = 0;
+          DUPall = __ballot((eq & ~(1ull << lane)) != 0);
+          DUP = __ballot((eq & lanes_below(lane)) != 0);
+        }
+        // LDS table: speculative insert of all 64 positions + read-back
+        asm volatile("" ::: "memory");
+        if (!GUEST && e1) table[h] = (E)A1;
+        asm volatile("" ::: "memory");
+        const uint32_t rb = (!GUEST && e1) ? (uint32_t)table[h] : (A1 & kEMask);
+        asm volatile("" ::: "memory");
+        const bool loser = rb != (A1 & kEMask);
+        const uint64_t LM = GUEST ? 0ull : __ballot(loser);
+        if (!GUEST) DUPall = LM;
         if (LM) {
           const int wl = (int)((rb - (W + (uint32_t)B + 1u)) & kEMask);  // lane that owns the slot
           uint64_t m = LM;
@@ -556,13 +575,19 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
         // un-inserted lanes and every DUP lane restore the old value, then the inserted DUP
         // lanes write in position order so that the latest one wins.
         asm volatile("" ::: "memory");
-        if (e1 && (((DUPall | ~INS) >> lane) & 1)) table[h] = (E)old;
-        uint64_t dm = DUPall & INS;
-        while (dm) {
-          const int k = __builtin_ctzll(dm);
-          asm volatile("" ::: "memory");
-          if (lane == k) table[h] = (E)A1;
-          dm &= dm - 1;
+        if (GUEST) {
+          // the table is still untouched: the inserted lanes write, and where several share a
+          // slot only the last of them (position order: the latest insert wins)
+          if (e1 && ((INS >> lane) & 1) && (eq & INS & ~lanes_upto(lane)) == 0) table[h] = (E)A1;
+        } else {
+          if (e1 && (((DUPall | ~INS) >> lane) & 1)) table[h] = (E)old;
+          uint64_t dm = DUPall & INS;
+          while (dm) {
+            const int k = __builtin_ctzll(dm);
+            asm volatile("" ::: "memory");
+            if (lane == k) table[h] = (E)A1;
+            dm &= dm - 1;
+          }
         }
         asm volatile("" ::: "memory");
         STAMP(t4);
@@ -612,9 +637,22 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
         // commit the inserts of lanes <= first valid lane; detect same-slot collisions
         const int lim = f0 < nexist - 1 ? f0 : nexist - 1;
         const bool ins = lane <= lim;
-        if (ins) vtable[h] = (E)A1;
-        const uint32_t rb = ins ? (uint32_t)vtable[h] : (A1 & kEMask);
-        const uint64_t C = __ballot(rb != (A1 & kEMask));
+        uint64_t C;
+        if (GUEST) {  // same-slot lanes among the inserted ones by ballots (see the dense batch)
+          uint64_t eqs = __ballot(ins);
+#pragma unroll
+          for (int k = 0; k < kTableBits; ++k) {
+            const bool bit = (h >> k) & 1u;
+            const uint64_t m = __ballot(bit);
+            eqs &= bit ? m : ~m;
+          }
+          C = __ballot(ins && (eqs & ~(1ull << lane)) != 0);
+          if (C == 0 && ins) vtable[h] = (E)A1;
+        } else {
+          if (ins) vtable[h] = (E)A1;
+          const uint32_t rb = ins ? (uint32_t)vtable[h] : (A1 & kEMask);
+          C = __ballot(rb != (A1 & kEMask));
+        }
 
         int f = f0;
         uint32_t cand = 0;  // absolute candidate position
@@ -622,7 +660,7 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
           if (f0 < 64) cand = rdlane(cand_abs, f0);
         } else {
           // two lanes of this batch share a slot: replay the batch in order
-          if (ins) vtable[h] = (E)old;
+          if (!GUEST && ins) vtable[h] = (E)old;
           f = 64;
           for (int e2 = 0; e2 < nexist; ++e2) {
             const uint32_t he = rdlane(h, e2);
@@ -724,7 +762,7 @@ __global__ __launch_bounds__(64) void lz77_guest_kernel(LzParams P) {
     q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
     if (q >= P.queue_end) break;
     __syncthreads();
-    lz77_stream<MULTI>(P, P.stream_ids[q], table, lane);
+    lz77_stream<MULTI, true>(P, P.stream_ids[q], table, lane);
     __syncthreads();
   }
 }
