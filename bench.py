@@ -315,7 +315,7 @@ def bench_inflate(args, flate, eng, d_in, in_off, n, blen, world, rank, dev, dis
             "config": {"workload": "inflate %s%d x %d B streams per GPU, S-%s, output == input: %s"
                                    % ("ONE spliced stream of " if args.spliced else "", n, blen, args.kind, ok),
                        "stage_ms": {"inflate": round(k_ms, 3)}},
-            "roofline": {"bound": "hbm", "kernel": "inflate_simt_kernel" if n >= 2048 else "inflate_kernel",
+            "roofline": {"bound": "hbm", "kernel": "inflate_simt_kernel" if n > 2048 else "inflate_kernel",
                          "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": inflate_traffic(args, n, blen)},

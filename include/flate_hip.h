@@ -61,7 +61,7 @@ int flate_hip_set_stream(flate_hip_ctx *ctx, void *hip_stream);
  *   "resident_blocks"    persistent LDS-table wavefronts (default 5 per CU)
  *   "guest_min_streams"  batches smaller than this use one block per stream (default 4096)
  *   "inflate_simt_min_streams"  inflate batches at least this large decode one stream per LANE
- *                        (64 per wavefront) instead of one per wavefront (default 2048)
+ *                        (64 per wavefront) instead of one per wavefront (default 2049)
  *   "inflate_lanes"      streams per wavefront of that decoder: 0 = chosen from the batch size
  *                        (default), or 16 / 32 / 64 */
 int flate_hip_set_option(flate_hip_ctx *ctx, const char *name, int64_t value);

@@ -52,7 +52,10 @@ struct flate_hip_ctx {
   uint64_t h_total_bytes = 0;
   uint32_t num_cus = 256;
   int inflate_lanes = 0;  // streams per wavefront of that inflater: 0 = by batch size, or 16/32/64
-  uint32_t inflate_simt_min = 2048;  // batches at least this large use the lane-per-stream inflater
+  // batches at least this large use the lane-per-stream inflater: it takes ~30 ms for 64 KiB
+  // streams whatever the batch size, the wave-per-stream one ~13 ms per 1024 streams (measured:
+  // tools/inflate_crossover.py)
+  uint32_t inflate_simt_min = 2049;
   uint32_t resident_blocks = 1280;  // persistent LDS-table blocks (5 per CU x 256 CUs)
   uint32_t queue_init = 0;
   uint32_t debug_chunks = 0;

@@ -1,0 +1,21 @@
+"""Dev tool: time both inflate kernels at several batch sizes (64 KiB S-text streams)."""
+import importlib, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+flate = importlib.import_module("moonbit-flate_amd")
+import torch
+eng = flate.FlateEngine(0)
+eng.set_profiling(True)
+blen = 65536
+for n in [int(x) for x in sys.argv[1:]] or [512, 1024, 2048, 4096, 8192, 16384]:
+    d = torch.from_numpy(flate.synth("text", n, blen)).cuda()
+    off = flate.uniform_offsets(n, blen)
+    comp, coff = eng.deflate_batch(d, off)
+    out = torch.empty(n * blen, dtype=torch.uint8, device="cuda")
+    res = {}
+    for name, simt_min, lanes in (("wave", 1 << 30, 0), ("simt16", 0, 16), ("simt32", 0, 32), ("simt64", 0, 64)):
+        eng.set_option("inflate_simt_min_streams", simt_min)
+        eng.set_option("inflate_lanes", lanes)
+        for _ in range(2):
+            eng.inflate_batch(comp, coff, [blen] * n, out=out)
+        res[name] = round(eng.last_timing()["inflate"], 2)
+    print(n, res, flush=True)
