@@ -95,13 +95,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # FLATE_BENCH_BACKEND=gloo rehearses the N>1 control flow where RCCL has no peers (several
+    # ranks on one GPU); the driver's runs use nccl (= RCCL) with one GPU per rank.
+    backend = os.environ.get("FLATE_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist_mod.init_process_group("nccl", rank=rank, world_size=world,
+                                        device_id=torch.device("cuda", local_rank))
+        else:
+            dist_mod.init_process_group(backend, rank=rank, world_size=world)
         dist = dist_mod
     else:
         torch.cuda.set_device(local_rank)
@@ -178,7 +186,7 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -280,7 +288,7 @@ def bench_inflate(args, flate, eng, d_in, in_off, n, blen, world, rank, dev, dis
     sync_all()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ok = bool((status == 0).all()) and bool(torch.equal(out, d_in))  # round-trip property, full size

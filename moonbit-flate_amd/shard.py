@@ -42,6 +42,12 @@ def gather_compressed(dist, local_buf, local_off, buf=None, pad_to=1 << 20, wait
     metadata and the payload padded to the largest shard (all_gather needs equal counts)."""
     import torch
     world = dist.get_world_size()
+    if dist.get_backend() == "gloo" and local_buf.is_cuda:
+        # rehearsal of the multi-GPU path on a box without RCCL peers (bench.py
+        # FLATE_BENCH_BACKEND=gloo): gloo moves host memory, so stage through the CPU
+        g = gather_compressed(dist, local_buf.cpu(), local_off, buf=None, pad_to=pad_to, wait=True)
+        g.buf = g.buf.to(local_buf.device)
+        return g
     dev = local_buf.device
     k = int(local_off.size - 1)
     clen = int(local_off[-1])
