@@ -594,7 +594,7 @@ int flate_hip_lz77_matches(flate_hip_ctx *c, const uint8_t *in, const uint64_t *
   return collect_timing(c, used);
 }
 
-#if defined(FLATE_LZ_STAMPS) || defined(FLATE_HP_STAMPS)
+#if defined(FLATE_LZ_STAMPS)
 // diagnostic builds only: per-chunk phase cycle sums of the last match-finder launch
 int flate_hip_debug_lz_stamps(flate_hip_ctx *c, uint64_t *out, uint32_t max_chunks) {
   uint32_t k = c->debug_chunks < max_chunks ? c->debug_chunks : max_chunks;
