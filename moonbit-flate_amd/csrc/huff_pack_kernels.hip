@@ -35,14 +35,6 @@ constexpr int kRing = 512;  // dwords in the LDS bit ring (a 256-position tile a
 constexpr int kTile = 256;  // input positions per walk step: 4 consecutive positions per lane
 constexpr int kHdrMax = 704;
 
-#ifdef FLATE_HP_STAMPS
-#define HSTAMP(var) const uint64_t var = __builtin_amdgcn_s_memtime()
-#define HSTAMP_ADD(i, t1, t0) do { if (lane == 0) sh.st[i] += (t1) - (t0); } while (0)
-#else
-#define HSTAMP(var)
-#define HSTAMP_ADD(i, t1, t0)
-#endif
-
 // codegen_order, huffman-bit-writer.mbt:83-85 (RFC 1951 3.2.7)
 __constant__ uint8_t kCodegenOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
