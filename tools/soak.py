@@ -1,0 +1,55 @@
+"""Dev tool: randomized parity soak on the GPU box -- every path against the oracle.
+    python tools/soak.py [seconds] [seed]"""
+import importlib, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+flate = importlib.import_module("moonbit-flate_amd")
+from oracle import pyoracle as O
+from util import make_streams
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+kinds = ["text", "ramp", "zero", "rand", "low", "period", "runs"]
+sizes = [0, 1, 2, 15, 16, 17, 18, 100, 127, 128, 129, 500, 4000, 30000, 65534, 65535, 65536, 65537, 65551,
+         65552, 66000, 100000, 131070, 131071, 131072, 200000, 262144, 400000]
+eng = flate.FlateEngine(0)
+t0, rounds, streams, nbytes = time.time(), 0, 0, 0
+while time.time() - t0 < budget:
+    n = int(rng.integers(1, 90))
+    specs = [(kinds[int(rng.integers(len(kinds)))], int(rng.choice(sizes)) if rng.random() < 0.7
+              else int(rng.integers(0, 300000))) for _ in range(n)]
+    seed = int(rng.integers(1 << 30))
+    data, off = make_streams(specs, seed=seed)
+    go = bool(rng.integers(2))
+    guests = bool(rng.integers(2))
+    eng.set_option("guest_min_streams", 1 if guests else 1 << 30)
+    eng.set_option("guest_blocks", int(rng.choice([8, 64, 256])) if guests else 0)
+    cm = O.COMPAT_GO if go else O.COMPAT_MOONBIT
+    tag = "seed=%d go=%s guests=%s n=%d" % (seed, go, guests, n)
+    out, ooff = eng.deflate_batch(data, off, compat_go=go)
+    ref, roff, rlen = O.deflate_batch(data, off, compat=cm, nthreads=8)
+    for i in range(n):
+        a = bytes(out[int(ooff[i]):int(ooff[i + 1])])
+        b = bytes(ref[int(roff[i]):int(roff[i]) + int(rlen[i])])
+        assert a == b, "deflate stream %d differs (%s, spec %s)" % (i, tag, specs[i])
+    one, nb, bit_off = eng.deflate_spliced(data, off, compat_go=go)
+    rs, rbo = O.deflate_spliced(data, off, cm)
+    assert bytes(one[:nb]) == rs and np.array_equal(bit_off, rbo), "spliced differs (%s)" % tag
+    szs = [s for _, s in specs]
+    comp = np.concatenate([out[:int(ooff[-1])], np.zeros(8, np.uint8)])
+    for simt_min in (0, 1 << 30):
+        eng.set_option("inflate_simt_min_streams", simt_min)
+        eng.set_option("inflate_lanes", int(rng.choice([0, 16, 32, 64])))
+        back, _, olen, status, _ = eng.inflate_batch(comp, ooff, szs)
+        assert (status == 0).all() and list(olen) == szs, "inflate status (%s)" % tag
+        assert bytes(back[:int(off[-1])]) == data[:int(off[-1])].tobytes(), "inflate bytes (%s)" % tag
+    back, _, olen, status, _ = eng.inflate_spliced(np.concatenate([one[:nb], np.zeros(8, np.uint8)]), nb, bit_off, szs)
+    assert (status == 0).all() and bytes(back[:int(off[-1])]) == data[:int(off[-1])].tobytes(), "inflate_spliced (%s)" % tag
+    rounds += 1
+    streams += n
+    nbytes += int(off[-1])
+    if rounds % 10 == 0:
+        print("round %d: %d streams, %.1f MB ok (%.0f s)" % (rounds, streams, nbytes / 1e6, time.time() - t0), flush=True)
+print("SOAK OK: %d rounds, %d streams, %.1f MB, %.0f s" % (rounds, streams, nbytes / 1e6, time.time() - t0))
