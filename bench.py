@@ -74,7 +74,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-streams", type=int, default=16384,
                     help="streams of the workload the CPU oracle is timed on (about 10 CPU-seconds per GiB)")
-    ap.add_argument("--verify", type=int, default=64, help="streams checked against the oracle")
+    ap.add_argument("--verify", type=int, default=1,
+                    help="0 = skip comparing the GPU output with the oracle's in the cpu_baseline leg")
     ap.add_argument("--no-guests", action="store_true",
                     help="match finder with LDS-table blocks only (no L2-table guest blocks); the "
                          "configuration the PMC traffic figure in profiles/ was collected on")
@@ -193,26 +194,17 @@ def main():
     clen = int(out_off[-1])
     ratio = in_bytes / clen
 
-    # parity spot check against the oracle (never part of the timed region)
+    # cpu_baseline leg (rank 0, N=1, outside the timed region): the oracle compresses the same
+    # streams on the host cores; its output is also the checker -- every stream it produced is
+    # compared with what the GPU wrote.
     verified = 0
-    if rank == 0 and args.verify > 0 and not args.spliced:  # (spliced output: tests/test_splice.py)
-        from oracle import pyoracle
-        o_cpu = out[:clen].cpu().numpy()
-        idx = np.linspace(0, n - 1, min(args.verify, n)).astype(int)
-        for i in idx:
-            want = pyoracle.deflate(host[i * blen:(i + 1) * blen])
-            got = bytes(o_cpu[int(out_off[i]):int(out_off[i + 1])])
-            if got != want:
-                raise SystemExit("PARITY FAILURE at stream %d" % i)
-            verified += 1
-
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import pyoracle
         ns = min(args.cpu_sample_streams, n)
         cores = min(os.cpu_count() or 1, 16)
         t1 = time.perf_counter()
-        _, _, o_len = pyoracle.deflate_batch(host[:ns * blen], in_off[:ns + 1], nthreads=cores)
+        o_buf, o_off, o_len = pyoracle.deflate_batch(host[:ns * blen], in_off[:ns + 1], nthreads=cores)
         cdt = time.perf_counter() - t1
         cpu_baseline = {
             "value": round(ns * blen / cdt / 2**30, 4), "unit": "GiB/s", "cores": cores,
@@ -220,6 +212,14 @@ def main():
             "sample": "first %d of %d streams (%d MiB), oracle C restatement, %d threads, %.1f s wall"
                       % (ns, n, ns * blen >> 20, cores, cdt),
         }
+        if not args.spliced and args.verify:  # (spliced output is checked by tests/test_splice.py)
+            g_cpu = out[:clen].cpu().numpy()
+            for i in range(ns):
+                a0, a1 = int(out_off[i]), int(out_off[i + 1])
+                b0 = int(o_off[i])
+                if a1 - a0 != int(o_len[i]) or not np.array_equal(g_cpu[a0:a1], o_buf[b0:b0 + a1 - a0]):
+                    raise SystemExit("PARITY FAILURE at stream %d" % i)
+            verified = ns
 
     if rank == 0:
         steps = args.steps

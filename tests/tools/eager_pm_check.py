@@ -1,7 +1,7 @@
 """Dev check: eager (level-parallel) package-merge == oracle bit_counts (huffman-code.mbt:112-244)."""
 import sys
 import numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, '.')  # run from the repository root: python tests/tools/eager_pm_check.py
 from oracle import pyoracle as o
 
 

@@ -1,8 +1,8 @@
 """Dev tool: randomized parity soak on the GPU box -- every path against the oracle.
-    python tools/soak.py [seconds] [seed]"""
+    python tests/tools/soak.py [seconds] [seed]"""
 import importlib, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 flate = importlib.import_module("moonbit-flate_amd")
