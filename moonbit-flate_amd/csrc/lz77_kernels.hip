@@ -569,7 +569,12 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
         // match records of this batch, in position order, one coalesced store
         if ((MF >> lane) & 1) acc_len += (uint32_t)tot_self;
         if ((M >> lane) & 1)
-          mout[nm + (uint32_t)__popcll(M & lanes_below(lane))] = make_uint2((uint32_t)q, rec_tok);
+          {  // streaming store: the records are read again only by the entropy kernels, and
+             // keeping them out of L2 leaves more of it to the guest blocks' hash tables
+            const unsigned long long rec = (unsigned long long)(uint32_t)q | ((unsigned long long)rec_tok << 32);
+            __builtin_nontemporal_store(
+                rec, reinterpret_cast<unsigned long long *>(mout + nm + (uint32_t)__popcll(M & lanes_below(lane))));
+          }
         nm += (uint32_t)__popcll(M);
         // commit: slots of non-DUP lanes already hold their position (speculative write);
         // un-inserted lanes and every DUP lane restore the old value, then the inserted DUP
