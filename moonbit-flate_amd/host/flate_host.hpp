@@ -229,7 +229,18 @@ struct BytesReader : ByteSource {  // @io.Buffer used as source
 // (ioeof at a clean end) together with the last bytes, nothing but the error afterwards.
 class Reader {
  public:
-  Reader(ByteSource &r, Engine &e, uint64_t size_hint = 0) : r_(r), e_(e), hint_(size_hint) {}
+  Reader(ByteSource &r, Engine &e, uint64_t size_hint = 0) : r_(&r), e_(e), hint_(size_hint) {}
+
+  // Decompressor::reset (inflate.mbt:862-884; without a preset dictionary, which is outside the
+  // scope table): forget everything and decode the stream `r` delivers next.
+  void reset(ByteSource &r, uint64_t size_hint = 0) {
+    r_ = &r;
+    hint_ = size_hint;
+    decoded_ = false;
+    data_.clear();
+    pos_ = 0;
+    err_ = std::nullopt;
+  }
 
   std::pair<int, Err> read(uint8_t *p, size_t n) {
     if (!decoded_) decode();
@@ -253,7 +264,7 @@ class Reader {
     std::vector<uint8_t> src;
     uint8_t tmp[4096];
     for (;;) {
-      auto r = r_.read(tmp, sizeof tmp);
+      auto r = r_->read(tmp, sizeof tmp);
       src.insert(src.end(), tmp, tmp + r.first);
       if (r.second) {
         if (!(*r.second == ioeof())) {
@@ -281,7 +292,7 @@ class Reader {
       return;
     }
   }
-  ByteSource &r_;
+  ByteSource *r_;
   Engine &e_;
   uint64_t hint_;
   bool decoded_ = false;

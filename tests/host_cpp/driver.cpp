@@ -56,6 +56,14 @@ int main() {
     Err ce = r.close();
     printf("rclose %s\n", ce ? ce->msg.c_str() : "none");
     hex("plain", got);
+    // Decompressor::reset (inflate.mbt:862): the same object decodes another stream afterwards
+    BytesReader src2(out[2]);
+    r.reset(src2);
+    std::vector<uint8_t> big(200);
+    auto r2 = r.read(big.data(), big.size());
+    size_t nz = 0;
+    for (int k = 0; k < r2.first; ++k) nz += big[k] != 0;
+    printf("reset %d %s %zu\n", r2.first, r2.second ? r2.second->msg.c_str() : "none", nz);
   }
   // a corrupt stream: reserved block type in the first header (bits 1,1,1)
   {

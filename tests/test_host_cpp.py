@@ -57,6 +57,7 @@ def test_host_mirror_matches_reference_behaviour(oracle):
     # Decompressor::read hands out data first and the error with the last bytes (inflate.mbt:382-405)
     assert reads == ["7 none", "7 none", "7 none", "7 EOF", "0 EOF", "0 EOF", "0 EOF"]
     assert lines["rclose"] == "none"                                    # :410-415
+    assert lines["reset"] == "100 EOF 0"                                # Decompressor::reset, :862
     assert bytes.fromhex(lines["plain"]) == b"hello worldhello again world"
     rc, _, _, err_off = oracle.inflate(bytes([7]) + want[1:], 100, full=True)
     assert rc == oracle.E_CORRUPT
