@@ -1,7 +1,19 @@
 """Multi-GPU row of the scope table: independent streams shard by contiguous
 index range, one process per GPU, no collective in the compress path; the only exchange step is
-the concatenation of the compressed shards (RCCL all-gather over xGMI, `nccl` backend; `gloo` on
-CPU for tests)."""
+the concatenation of the compressed shards (RCCL over xGMI, `nccl` backend; `gloo` on CPU for
+tests).
+
+Two forms of the exchange (SURVEY section 5 asks for both to be reported):
+
+* mode="allgather": one `all_gather_into_tensor` of every rank's payload padded to a common size
+  plus one fused `all_gather_into_tensor` of the metadata (size, stream count, per-stream index).
+  Nothing on the issue path waits for the GPU or for a peer: the pad is *sticky* (agreed once, at
+  the first call or after an overflow) and the metadata is read on the host only when the result
+  is consumed (`wait()`), so the gather of batch k really overlaps the compression of batch k+1.
+* mode="sendrecv": grouped `isend/irecv` of the exact sizes to and from every peer, all xGMI
+  links at once instead of a ring; the sizes must be known before the receives are posted, so
+  this form reads the 16-byte-per-rank size vector on the host first.
+"""
 import numpy as np
 
 
@@ -10,75 +22,143 @@ def shard_range(n_streams, rank, world):
     return n_streams * rank // world, n_streams * (rank + 1) // world
 
 
+def max_shard_streams(n_streams, world):
+    """Largest stream count any rank gets from shard_range (known without communication)."""
+    return max(shard_range(n_streams, r, world)[1] - shard_range(n_streams, r, world)[0]
+               for r in range(world)) if world > 0 else 0
+
+
+class GatherPlan:
+    """What all ranks must agree on before a sync-free gather: the padded payload size and the
+    largest per-rank stream count.  `pad` only grows; every rank computes the same value because it
+    is derived from the gathered metadata of the same batch."""
+
+    def __init__(self, kmax, pad=0, pad_to=1 << 20):
+        self.kmax, self.pad, self.pad_to = int(kmax), int(pad), int(pad_to)
+
+    def round(self, nbytes):
+        return max((int(nbytes) + self.pad_to - 1) // self.pad_to * self.pad_to, self.pad_to)
+
+
 class GatheredStreams:
     """All ranks' compressed streams on this rank: rank r's payload sits at buf[r*pad : r*pad+size[r]],
     global stream j (rank-major order) at buf[off[j] : off[j] + length[j]]."""
 
-    def __init__(self, buf, pad, sizes, counts, off, length, work=None):
-        self.buf, self.pad, self.sizes, self.counts, self.off, self.length = \
-            buf, pad, sizes, counts, off, length
-        self.work = work  # pending payload collective (gather_compressed(..., wait=False)) or None
+    def __init__(self, buf, pad, world, kmax, metas=None, works=(), keep=(), plan=None):
+        self.buf, self.pad, self.world, self.kmax, self.plan = buf, pad, world, kmax, plan
+        self._metas = metas      # device/host int64[world * (kmax + 3)], resolved lazily
+        self._works = list(works)
+        self._keep = keep        # tensors that must outlive the collectives
+        self._resolved = False
+        self.sizes = self.counts = self.off = self.length = None
+        self.overflow = False    # some rank's payload did not fit `pad` (caller must redo)
 
     def wait(self):
-        """Make the current stream (and for gloo the host) wait for the payload; idempotent."""
-        if self.work is not None:
-            self.work.wait()
-            self.work = None
+        """Wait for the collectives and resolve the index on the host; idempotent."""
+        for w in self._works:
+            w.wait()
+        self._works = []
+        if not self._resolved:
+            m = self._metas.cpu().numpy().reshape(self.world, self.kmax + 3)
+            self.sizes, self.counts = m[:, 0].copy(), m[:, 1].copy()
+            self.overflow = bool((self.sizes > self.pad).any())
+            if self.overflow and self.plan is not None:  # every rank raises it to the same value
+                self.plan.pad = max(self.plan.pad, self.plan.round(int(self.sizes.max())))
+            off, length = [], []
+            for r in range(self.world):
+                o = m[r, 2:2 + int(self.counts[r]) + 1].astype(np.uint64)
+                off.append(o[:-1] + np.uint64(r * self.pad))
+                length.append(o[1:] - o[:-1])
+            self.off = np.concatenate(off) if off else np.zeros(0, np.uint64)
+            self.length = np.concatenate(length) if length else np.zeros(0, np.uint64)
+            self._resolved = True
+            self._keep = ()
         return self
 
     def stream(self, j):
+        self.wait()
         o = int(self.off[j])
         return self.buf[o:o + int(self.length[j])]
 
 
-def gather_compressed(dist, local_buf, local_off, buf=None, pad_to=1 << 20, wait=True):
+def _meta_tensor(local_off, kmax, dev):
+    import torch
+    k = int(local_off.size - 1)
+    m = np.zeros(kmax + 3, dtype=np.int64)
+    m[0], m[1] = int(local_off[-1]), k
+    m[2:2 + k + 1] = local_off.astype(np.int64)
+    return torch.from_numpy(m).to(dev)
+
+
+def gather_compressed(dist, local_buf, local_off, buf=None, plan=None, pad_to=1 << 20, wait=True,
+                      mode="allgather"):
     """Concatenate every rank's compressed shard on every rank.
 
-    wait=False leaves the payload all-gather in flight (call .wait() on the result before reading
-    buf or overwriting local_buf): the next batch can then be compressed while xGMI moves this one.
-
     local_buf: torch uint8 tensor holding this rank's streams back to back (may be larger than the
-    payload); local_off: numpy uint64[k+1] offsets.  Uses two all-gathers: the (size, count, index)
-    metadata and the payload padded to the largest shard (all_gather needs equal counts)."""
+    payload); local_off: numpy uint64[k+1] offsets.  `plan` (GatherPlan) carries the sticky pad
+    between calls; without one a blocking size exchange agrees on it first.  wait=False leaves the
+    collectives in flight (call .wait() on the result before reading buf or overwriting
+    local_buf).  If result.overflow is set after wait(), a payload exceeded plan.pad: plan.pad has
+    been raised and the call must be repeated for that batch."""
     import torch
     world = dist.get_world_size()
     if dist.get_backend() == "gloo" and local_buf.is_cuda:
         # rehearsal of the multi-GPU path on a box without RCCL peers (bench.py
         # FLATE_BENCH_BACKEND=gloo): gloo moves host memory, so stage through the CPU
-        g = gather_compressed(dist, local_buf.cpu(), local_off, buf=None, pad_to=pad_to, wait=True)
+        g = gather_compressed(dist, local_buf.cpu(), local_off, buf=None, plan=plan, pad_to=pad_to,
+                              wait=True, mode=mode)
         g.buf = g.buf.to(local_buf.device)
         return g
     dev = local_buf.device
     k = int(local_off.size - 1)
     clen = int(local_off[-1])
-    meta = torch.tensor([clen, k], dtype=torch.int64, device=dev)
-    metas = torch.empty(2 * world, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(metas, meta)
-    metas = metas.cpu().numpy().reshape(world, 2)
-    sizes, counts = metas[:, 0].copy(), metas[:, 1].copy()
-    pad = (int(sizes.max()) + pad_to - 1) // pad_to * pad_to
-    pad = max(pad, pad_to)
-    kmax = int(counts.max())
-    # per-stream index of every rank (padded to kmax+1 entries)
-    idx = torch.zeros(kmax + 1, dtype=torch.int64, device=dev)
-    idx[:k + 1] = torch.from_numpy(local_off.astype(np.int64)).to(dev)
-    idxs = torch.empty(world * (kmax + 1), dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(idxs, idx)
-    idxs = idxs.cpu().numpy().reshape(world, kmax + 1)
-    # payload
-    if local_buf.numel() < pad:
-        grown = torch.zeros(pad, dtype=torch.uint8, device=dev)
-        grown[:local_buf.numel()] = local_buf
-        local_buf = grown
+    if plan is None:
+        plan = GatherPlan(kmax=0, pad=0, pad_to=pad_to)
+    if plan.pad == 0 or plan.kmax == 0 or mode == "sendrecv":
+        # blocking agreement on (largest payload, largest stream count): 16 bytes per rank
+        mine = torch.tensor([clen, k], dtype=torch.int64, device=dev)
+        every = torch.empty(2 * world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(every, mine)
+        every = every.cpu().numpy().reshape(world, 2)
+        plan.pad = max(plan.pad, plan.round(every[:, 0].max()))
+        plan.kmax = max(plan.kmax, int(every[:, 1].max()))
+        peer_sizes = every[:, 0]
+    if k > plan.kmax:
+        raise ValueError("rank holds %d streams, plan allows %d" % (k, plan.kmax))
+    pad, kmax = plan.pad, plan.kmax
+    meta = _meta_tensor(local_off, kmax, dev)
+    metas = torch.empty(world * (kmax + 3), dtype=torch.int64, device=dev)
+    works = [dist.all_gather_into_tensor(metas, meta, async_op=True)]
     if buf is None or buf.numel() < pad * world:
         buf = torch.empty(pad * world, dtype=torch.uint8, device=dev)
-    work = dist.all_gather_into_tensor(buf[:pad * world], local_buf[:pad], async_op=True)
+    keep = [meta]
+    if mode == "allgather":
+        if local_buf.numel() < pad:
+            grown = torch.zeros(pad, dtype=torch.uint8, device=dev)
+            grown[:local_buf.numel()] = local_buf
+            local_buf = grown
+        keep.append(local_buf)
+        works.append(dist.all_gather_into_tensor(buf[:pad * world], local_buf[:pad], async_op=True))
+    elif mode == "sendrecv":
+        rank = dist.get_rank()
+        ops = []
+        for r in range(world):
+            if r == rank:
+                continue
+            if clen:
+                ops.append(dist.P2POp(dist.isend, local_buf[:clen], r))
+            if int(peer_sizes[r]):
+                ops.append(dist.P2POp(dist.irecv, buf[r * pad:r * pad + int(peer_sizes[r])], r))
+        buf[rank * pad:rank * pad + clen].copy_(local_buf[:clen])
+        keep.append(local_buf)
+        if ops:
+            works.extend(dist.batch_isend_irecv(ops))
+    else:
+        raise ValueError("mode must be 'allgather' or 'sendrecv'")
+    g = GatheredStreams(buf, pad, world, kmax, metas=metas, works=works, keep=tuple(keep), plan=plan)
     if wait:
-        work.wait()
-        work = None
-    off, length = [], []
-    for r in range(world):
-        o = idxs[r, :counts[r] + 1].astype(np.uint64)
-        off.append(o[:-1] + np.uint64(r * pad))
-        length.append(o[1:] - o[:-1])
-    return GatheredStreams(buf, pad, sizes, counts, np.concatenate(off), np.concatenate(length), work)
+        g.wait()
+        if g.overflow:  # a payload outgrew the sticky pad (raised by wait()): repeat
+            return gather_compressed(dist, local_buf, local_off, buf=None, plan=plan, pad_to=pad_to,
+                                     wait=True, mode=mode)
+    return g

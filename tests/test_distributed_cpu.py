@@ -47,6 +47,18 @@ def _worker(rank, world, port, n_streams, q):
     g0.wait()
     g1.wait().wait()
     ok = torch.equal(g1.buf[:g.pad * world], g.buf[:g.pad * world])
+    # sticky plan: after the first (blocking) agreement nothing on the issue path syncs; a payload
+    # that outgrows the pad is reported as overflow by every rank and repeated with a larger pad
+    plan = shard.GatherPlan(kmax=shard.max_shard_streams(n_streams, world), pad=4096, pad_to=4096)
+    gp = shard.gather_compressed(dist, local, off, plan=plan, wait=False)
+    gp.wait()
+    ok = ok and gp.overflow and plan.pad >= int(gp.sizes.max())
+    gp = shard.gather_compressed(dist, local, off, plan=plan, wait=False).wait()
+    ok = ok and not gp.overflow and all(
+        bytes(gp.stream(j).numpy()) == bytes(g.stream(j).numpy()) for j in range(n_streams))
+    # grouped isend/irecv of the exact sizes (all peers at once)
+    gs = shard.gather_compressed(dist, local, off, plan=plan, mode="sendrecv")
+    ok = ok and all(bytes(gs.stream(j).numpy()) == bytes(g.stream(j).numpy()) for j in range(n_streams))
     # every rank must now hold every stream, in global order, bit-exact
     for j in range(n_streams):
         want = pyoracle.deflate(flate.synth("text", 1, lens[j], first_stream=j))
@@ -84,3 +96,34 @@ def test_shard_range_partitions_exactly():
             r = [shard.shard_range(n, k, w) for k in range(w)]
             assert r[0][0] == 0 and r[-1][1] == n
             assert all(r[k][1] == r[k + 1][0] for k in range(w - 1))
+
+
+def test_bench_spawns_its_own_ranks_and_verifies_the_gathered_buffer():
+    """`bench.py --gpus 2` with no WORLD_SIZE starts two ranks itself; rank 0 prints one JSON line
+    with n_gpus = 2, both exchange forms timed and a sample of the gathered buffer checked against
+    the oracle.  Runs on CPU through the test engine (gloo)."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["FLATE_BENCH_TEST_ENGINE"] = "tests.cpu_engine:OracleEngine"
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "1", "--streams", "128", "--stream-len", "4096"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 2
+    assert line["config"]["parity_checked_streams"] >= 64
+    g = line["config"]["gather"]
+    assert g["allgather_ms"]["min"] > 0 and g["sendrecv_ms"]["min"] > 0 and g["bytes_received_per_gpu"] > 0
+    assert line["cpu_baseline"]["value"] > 0 and "TEST-ENGINE" in line["data"]
+
+
+def test_bench_rejects_a_world_size_that_contradicts_gpus():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
