@@ -37,6 +37,10 @@ typedef struct flate_hip_ctx flate_hip_ctx;
 #define FLATE_HIP_E_TOO_LARGE (-6)      /* stream >= 2 GiB - 128 KiB (buffer_reset,
                                            deflate-fast.mbt:55: shift_offsets not built) */
 #define FLATE_HIP_E_UNEXPECTED_EOF (-7) /* inflate: err_unexpected_eof (inflate.mbt:781) */
+#define FLATE_HIP_E_INTERNAL (-8)       /* encoder self-check failed (the reference abort()s on its
+                                           invariants, deflate.mbt:111, huffman-code.mbt:118,232):
+                                           packed bits != the size computed before packing;
+                                           flate_hip_last_hip_error names the stream            */
 
 /* flags */
 #define FLATE_HIP_DEVICE_PTRS 0x1u /* in/out (and tokens/recs) are device pointers; offset

@@ -46,7 +46,6 @@ struct flate_hip_ctx {
   hipStream_t guest_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int guest_blocks = 0;      // 0 = guest kernel off
-  float guest_share = 0.f;   // fraction of the single-window streams given to the guests
   uint32_t guest_min = 4096; // below this many streams the guests stay idle
   int32_t h_status_word = 0;  // landing pads of small async D2H copies
   uint64_t h_total_bytes = 0;
@@ -287,6 +286,7 @@ const char *flate_hip_strerror(int code) {
     case FLATE_HIP_E_NO_DEVICE: return "no usable HIP device (this engine has no CPU path)";
     case FLATE_HIP_E_TOO_LARGE: return "stream too large";
     case FLATE_HIP_E_UNEXPECTED_EOF: return "unexpected EOF";
+    case FLATE_HIP_E_INTERNAL: return "internal error: encoder self-check failed";
     default: return "unknown error";
   }
 }
@@ -314,14 +314,14 @@ int flate_hip_init(int device, flate_hip_ctx **out) {
   flate_hip_ctx *c = new flate_hip_ctx();
   c->device = device;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->own_stream) != hipSuccess) {
-    delete c;
+    flate_hip_destroy(c);
     return FLATE_HIP_E_NO_DEVICE;
   }
   c->stream = c->own_stream;
   if (hipStreamCreateWithFlags(&c->guest_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
-    delete c;
+    flate_hip_destroy(c);
     return FLATE_HIP_E_HIP;
   }
   {  // 5 resident (LDS-table) + 5 guest (L2-table) match-finder waves per CU (measured best)
@@ -333,13 +333,12 @@ int flate_hip_init(int device, flate_hip_ctx **out) {
     c->resident_blocks = 5u * (uint32_t)cus;
     c->guest_blocks = 5 * cus;
   }
-  if (const char *e = getenv("FLATE_HIP_GUEST_BLOCKS")) c->guest_blocks = atoi(e);
-  if (const char *e = getenv("FLATE_HIP_GUEST_SHARE")) c->guest_share = (float)atof(e);
+  if (const char *e = getenv("FLATE_HIP_GUEST_BLOCKS")) c->guest_blocks = atoi(e) < 0 ? 0 : atoi(e);
   if (const char *e = getenv("FLATE_HIP_GUEST_MIN")) c->guest_min = (uint32_t)atoi(e);
-  if (const char *e = getenv("FLATE_HIP_RESIDENT_BLOCKS")) c->resident_blocks = (uint32_t)atoi(e);
+  if (const char *e = getenv("FLATE_HIP_RESIDENT_BLOCKS")) c->resident_blocks = atoi(e) < 1 ? 1u : (uint32_t)atoi(e);
   for (auto &e : c->ev)
     if (hipEventCreate(&e) != hipSuccess) {
-      delete c;
+      flate_hip_destroy(c);
       return FLATE_HIP_E_HIP;
     }
   std::vector<uint16_t> tab = make_scan_table();
@@ -513,7 +512,14 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
                               c->stream));
   HIP_TRY(c, hipMemcpyAsync(&c->h_status_word, c->d_status.p, 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if (c->h_status_word) return c->h_status_word;
+  if (c->h_status_word) {
+    if (c->h_status_word <= -0x100000) {  // encoder self-check (huff_pack_kernel): -(0x100000 + stream)
+      c->hip_err = "packed bits differ from the computed block size in stream " +
+                   std::to_string((uint32_t)(-c->h_status_word) - 0x100000u) + " (mod 2^20)";
+      return FLATE_HIP_E_INTERNAL;
+    }
+    return c->h_status_word;
+  }
   produced = spliced ? c->h_total_bytes : out_off[n];
   if (total_bytes) *total_bytes = produced;
   if (!dev) {

@@ -924,7 +924,7 @@ __global__ __launch_bounds__(64) void huff_pack_kernel(HuffParams P) {
     emit_stored(S, g.stream, 0, true, lane);  // Compressor::close (deflate.mbt:171-176)
   sink_finish(S, lane);
   // the sizes computed by huff_code_kernel and the bits actually written must agree
-  if (lane == 0 && S.bitpos - bit0 != out_bits) atomicExch(P.status, -3);
+  if (lane == 0 && S.bitpos - bit0 != out_bits) atomicExch(P.status, -(int)(0x100000u + (sid & 0xfffffu)));  // E_INTERNAL + stream
 }
 
 }  // namespace flate

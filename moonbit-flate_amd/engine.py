@@ -58,6 +58,22 @@ def _is_torch(x):
     return type(x).__module__.startswith("torch")
 
 
+def _check_out(out, data, need, what):
+    """A caller-supplied output buffer must be uint8, contiguous, on the same side (and device) as
+    the input and hold at least `need` bytes: the kernels bound their writes by the slot table,
+    not by the real size of `out`."""
+    if _is_torch(data):
+        import torch
+        ok = _is_torch(out) and out.dtype == torch.uint8 and out.is_contiguous() and \
+            out.device == data.device and out.numel() >= need
+    else:
+        ok = isinstance(out, np.ndarray) and out.dtype == np.uint8 and out.flags["C_CONTIGUOUS"] and \
+            out.size >= need
+    if not ok:
+        raise FlateError(E_INVALID, "%s: out must be a contiguous uint8 buffer of >= %d bytes on the "
+                                    "same device as the input" % (what, need))
+
+
 class FlateEngine:
     """One engine = one flate_hip_ctx = one GPU + one HIP stream."""
 
@@ -124,12 +140,16 @@ class FlateEngine:
             assert data.dtype == torch.uint8 and data.is_cuda and data.is_contiguous()
             if out is None:
                 out = torch.empty(max(int(out_cap), 16), dtype=torch.uint8, device=data.device)
+            else:
+                _check_out(out, data, 1, "deflate_batch")
             cap = out.numel()
             in_ptr, out_ptr = data.data_ptr(), out.data_ptr()
         else:
             data = np.ascontiguousarray(data, dtype=np.uint8)
             if out is None:
                 out = np.empty(max(int(out_cap), 16), dtype=np.uint8)
+            else:
+                _check_out(out, data, 1, "deflate_batch")
             cap = out.size
             in_ptr, out_ptr = data.ctypes.data, out.ctypes.data
         rc = self._L.flate_hip_deflate_fast_batch(self._ctx, in_ptr, in_off.ctypes.data, n, out_ptr,
@@ -156,11 +176,15 @@ class FlateEngine:
             assert data.dtype == torch.uint8 and data.is_cuda and data.is_contiguous()
             if out is None:
                 out = torch.empty(total, dtype=torch.uint8, device=data.device)
+            else:
+                _check_out(out, data, int(out_off[-1]), "inflate")
             in_ptr, out_ptr = data.data_ptr(), out.data_ptr()
         else:
             data = np.ascontiguousarray(data, dtype=np.uint8)
             if out is None:
                 out = np.zeros(total, dtype=np.uint8)
+            else:
+                _check_out(out, data, int(out_off[-1]), "inflate")
             in_ptr, out_ptr = data.ctypes.data, out.ctypes.data
         rc = self._L.flate_hip_inflate_batch(self._ctx, in_ptr, in_off.ctypes.data, n, out_ptr,
                                              out_off.ctypes.data, out_len.ctypes.data,
@@ -186,11 +210,15 @@ class FlateEngine:
             assert data.dtype == torch.uint8 and data.is_cuda and data.is_contiguous()
             if out is None:
                 out = torch.empty(cap, dtype=torch.uint8, device=data.device)
+            else:
+                _check_out(out, data, 8, "deflate_spliced")
             in_ptr, out_ptr, out_cap = data.data_ptr(), out.data_ptr(), out.numel()
         else:
             data = np.ascontiguousarray(data, dtype=np.uint8)
             if out is None:
                 out = np.zeros(cap, dtype=np.uint8)
+            else:
+                _check_out(out, data, 8, "deflate_spliced")
             in_ptr, out_ptr, out_cap = data.ctypes.data, out.ctypes.data, out.size
         self._check(self._L.flate_hip_deflate_fast_spliced(
             self._ctx, in_ptr, in_off.ctypes.data, n, out_ptr, out_cap, C.byref(out_len),
@@ -214,11 +242,15 @@ class FlateEngine:
             assert data.dtype == torch.uint8 and data.is_cuda and data.is_contiguous()
             if out is None:
                 out = torch.empty(total, dtype=torch.uint8, device=data.device)
+            else:
+                _check_out(out, data, int(out_off[-1]), "inflate")
             in_ptr, out_ptr = data.data_ptr(), out.data_ptr()
         else:
             data = np.ascontiguousarray(data, dtype=np.uint8)
             if out is None:
                 out = np.zeros(total, dtype=np.uint8)
+            else:
+                _check_out(out, data, int(out_off[-1]), "inflate")
             in_ptr, out_ptr = data.ctypes.data, out.ctypes.data
         rc = self._L.flate_hip_inflate_spliced(self._ctx, in_ptr, int(nbytes), bit_off.ctypes.data, n,
                                                out_ptr, out_off.ctypes.data, out_len.ctypes.data,
@@ -255,7 +287,7 @@ class FlateEngine:
 
 
 # status codes of inflate_batch (include/flate_hip.h)
-E_OUT_TOO_SMALL, E_CORRUPT, E_UNEXPECTED_EOF = -2, -4, -7
+E_INVALID, E_OUT_TOO_SMALL, E_CORRUPT, E_UNEXPECTED_EOF, E_INTERNAL = -1, -2, -4, -7, -8
 
 
 def lz_chunks(stream_len):
