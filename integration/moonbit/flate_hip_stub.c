@@ -14,6 +14,9 @@ flate_hip_ctx *flate_hip_mbt_ctx_new(int device) {
   return c;
 }
 
+/* MoonBit has no null test for an #external type */
+int flate_hip_mbt_ctx_is_null(const flate_hip_ctx *c) { return c == 0; }
+
 /* MoonBit Int64/UInt64 FixedArrays are passed as plain pointers: these two calls only fix the
  * argument order and types the .mbt file declares. */
 int flate_hip_mbt_deflate_batch(flate_hip_ctx *c, const uint8_t *in, const uint64_t *in_off, uint32_t n,
@@ -25,4 +28,11 @@ int flate_hip_mbt_inflate_batch(flate_hip_ctx *c, const uint8_t *in, const uint6
                                 uint8_t *out, const uint64_t *out_off, uint64_t *out_len, int32_t *status,
                                 int64_t *err_off, uint32_t flags) {
   return flate_hip_inflate_batch(c, in, in_off, n, out, out_off, out_len, status, err_off, flags);
+}
+
+/* out_len is a one-element FixedArray[UInt64] on the MoonBit side */
+int flate_hip_mbt_deflate_spliced(flate_hip_ctx *c, const uint8_t *in, const uint64_t *in_off, uint32_t n,
+                                  uint8_t *out, uint64_t out_cap, uint64_t *out_len, uint64_t *bit_off,
+                                  uint32_t flags) {
+  return flate_hip_deflate_fast_spliced(c, in, in_off, n, out, out_cap, out_len, bit_off, flags);
 }

@@ -7,12 +7,16 @@
 //   corrupt_input_error                   inflate.mbt:38
 // The reference is single-stream and synchronous; the GPU engine is a batch engine, so Writer
 // buffers write() calls (the 65535-byte staging window of deflate.mbt:222-229 makes the output a
-// function of the concatenated bytes only) and compresses in close().  BatchWriter closes many
-// streams with one kernel pipeline -- the intended way to use the engine.
+// function of the concatenated bytes only) and compresses in close().  BatchWriter (below) closes
+// many Writers with one kernel pipeline -- the intended way to use the engine -- and a Writer built
+// with chunk_bytes > 0 cuts ONE large stream into independent chunks that the GPU compresses in
+// parallel and splices into one legal DEFLATE stream (different bytes than a single
+// Writer would produce, same inflated result).
 #pragma once
 
 #include <algorithm>
 #include <cstdint>
+#include <memory>
 #include <optional>
 #include <string>
 #include <utility>
@@ -93,11 +97,21 @@ inline Err compress_batch(Engine &e, const std::vector<std::vector<uint8_t>> &st
   return std::nullopt;
 }
 
+inline Err compress_spliced(Engine &e, const std::vector<std::vector<uint8_t>> &streams,
+                            std::vector<uint8_t> &out, std::vector<uint64_t> *bit_off, uint32_t flags);
+
 // Writer (writer.mbt:2-15): write() appends to the stream, close() emits the DEFLATE bytes to the
 // sink given at construction.  Sticky error rules of Compressor (deflate.mbt:157-183,280-294).
+// chunk_bytes == 0 (default): the bytes a reference Writer produces, bit for bit.
+// chunk_bytes  > 0 (opt-in): the stream is cut into independent chunks of that many
+// bytes, each compressed as a fresh Writer would (no matches across chunk borders), all chunks in
+// one GPU batch, and emitted as ONE spliced DEFLATE stream.  Any inflater reads it back to the
+// same bytes, but it is NOT the byte sequence of a single Writer -- a one-wavefront stream gets no
+// parallelism on the GPU, this mode does.
 class Writer {
  public:
-  Writer(ByteSink &w, Engine &e, uint32_t flags = 0) : w_(w), e_(e), flags_(flags) {}
+  Writer(ByteSink &w, Engine &e, uint32_t flags = 0, size_t chunk_bytes = 0)
+      : w_(w), e_(e), flags_(flags), chunk_(chunk_bytes) {}
 
   std::pair<int, Err> write(const uint8_t *p, size_t n) {  // deflate.mbt:280-294
     if (err_) return {0, err_};
@@ -110,7 +124,16 @@ class Writer {
     if (err_ && *err_ == writer_closed_error()) return std::nullopt;
     if (err_) return err_;
     std::vector<std::vector<uint8_t>> out;
-    Err er = compress_batch(e_, {pending_}, out, flags_);
+    Err er;
+    if (chunk_ > 0 && pending_.size() > chunk_) {
+      std::vector<std::vector<uint8_t>> parts;
+      for (size_t o = 0; o < pending_.size(); o += chunk_)
+        parts.emplace_back(pending_.begin() + o, pending_.begin() + std::min(pending_.size(), o + chunk_));
+      out.resize(1);
+      er = compress_spliced(e_, parts, out[0], nullptr, flags_);
+    } else {
+      er = compress_batch(e_, {pending_}, out, flags_);
+    }
     if (er) {
       err_ = er;
       return err_;
@@ -128,14 +151,62 @@ class Writer {
   ByteSink &w_;
   Engine &e_;
   uint32_t flags_;
+  size_t chunk_;
   std::vector<uint8_t> pending_;
   Err err_;
+  friend class BatchWriter;
+};
+
+// Many Writers closed by ONE kernel pipeline: every stream still gets the bytes of its own
+// Writer::new / write / close (writer.mbt:10,45,53), but the GPU sees them as one batch.
+//   BatchWriter bw(engine);  Writer &a = bw.add(sink_a);  Writer &b = bw.add(sink_b);
+//   a.write(...); b.write(...);  bw.close_all();
+class BatchWriter {
+ public:
+  explicit BatchWriter(Engine &e, uint32_t flags = 0) : e_(e), flags_(flags) {}
+  Writer &add(ByteSink &sink) {
+    ws_.emplace_back(new Writer(sink, e_, flags_));
+    return *ws_.back();
+  }
+  size_t size() const { return ws_.size(); }
+  // close() of every Writer that is still open; returns the first error (each Writer keeps its
+  // own sticky state exactly as a lone close() would leave it)
+  Err close_all() {
+    std::vector<std::vector<uint8_t>> in, out;
+    std::vector<Writer *> open;
+    for (auto &w : ws_)
+      if (!w->err_) {
+        open.push_back(w.get());
+        in.push_back(std::move(w->pending_));
+      }
+    if (open.empty()) return std::nullopt;
+    Err er = compress_batch(e_, in, out, flags_);
+    Err first;
+    for (size_t i = 0; i < open.size(); ++i) {
+      Writer *w = open[i];
+      if (er) {
+        w->err_ = er;
+      } else {
+        auto r = w->w_.write(out[i].data(), out[i].size());
+        w->err_ = r.second ? r.second : Err(writer_closed_error());
+      }
+      if (!first && w->err_ && !(*w->err_ == writer_closed_error())) first = w->err_;
+    }
+    return first;
+  }
+
+ private:
+  Engine &e_;
+  uint32_t flags_;
+  std::vector<std::unique_ptr<Writer>> ws_;
 };
 
 // ---- spliced form (no reference counterpart): one DEFLATE stream for the batch ----
 inline Err compress_spliced(Engine &e, const std::vector<std::vector<uint8_t>> &streams,
                             std::vector<uint8_t> &out, std::vector<uint64_t> *bit_off = nullptr,
-                            uint32_t flags = 0) {
+                            uint32_t flags = 0);
+inline Err compress_spliced(Engine &e, const std::vector<std::vector<uint8_t>> &streams,
+                            std::vector<uint8_t> &out, std::vector<uint64_t> *bit_off, uint32_t flags) {
   if (!e.ok()) return make_error(e, e.status());
   const uint32_t n = (uint32_t)streams.size();
   std::vector<uint64_t> in_off(n + 1, 0), bo(n + 1, 0);

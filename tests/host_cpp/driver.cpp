@@ -99,5 +99,48 @@ int main() {
     for (size_t i = 0; i < back.size(); ++i) diff += back[i] != (i < 65536 ? in[1][i] : in[2][i - 65536]);
     printf("unspliced %s %zu %zu\n", de ? de->msg.c_str() : "none", back.size(), diff);
   }
+  // BatchWriter: three Writers closed by one kernel pipeline, each with its own sink and state
+  {
+    BatchWriter bw(eng);
+    Buffer s0, s1, s2;
+    Writer &w0 = bw.add(s0), &w1 = bw.add(s1), &w2 = bw.add(s2);
+    w0.write((const uint8_t *)d1, strlen(d1));
+    w0.write((const uint8_t *)d2, strlen(d2));
+    w1.write(in[1]);
+    (void)w2;  // nothing written: the empty stream
+    Err ce = bw.close_all();
+    printf("bw_close %s\n", ce ? ce->msg.c_str() : "none");
+    hex("bw0", s0.bytes);
+    hex("bw1", s1.bytes);
+    hex("bw2", s2.bytes);
+    auto ra = w0.write((const uint8_t *)d1, 3);
+    printf("bw_write_after_close %d %s\n", ra.first, ra.second ? ra.second->msg.c_str() : "none");
+    Err c2 = bw.close_all();
+    printf("bw_close2 %s\n", c2 ? c2->msg.c_str() : "none");
+  }
+  // opt-in chunked Writer: one 300000-byte stream cut into 65536-byte independent
+  // chunks, compressed in one batch, emitted as ONE spliced stream
+  {
+    std::vector<uint8_t> big(300000);
+    uint32_t x = 12345;
+    for (size_t i = 0; i < big.size(); ++i) {
+      x = x * 1664525u + 1013904223u;
+      big[i] = (uint8_t)("etaoin shrdlu"[(x >> 24) % 13]);
+    }
+    Buffer sink;
+    Writer cw(sink, eng, 0, 65536);
+    cw.write(big.data(), 100000);
+    cw.write(big.data() + 100000, 200000);
+    Err ce = cw.close();
+    printf("chunked %s %zu\n", ce ? ce->msg.c_str() : "none", sink.bytes.size());
+    hex("chunked_bytes", sink.bytes);
+    BytesReader src(sink.bytes);
+    Reader r(src, eng, 300000);
+    std::vector<uint8_t> back(300001);
+    auto rr = r.read(back.data(), back.size());
+    size_t diff = 0;
+    for (int k = 0; k < rr.first && k < 300000; ++k) diff += back[k] != big[k];
+    printf("chunked_back %d %s %zu\n", rr.first, rr.second ? rr.second->msg.c_str() : "none", diff);
+  }
   return 0;
 }

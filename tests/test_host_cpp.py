@@ -71,3 +71,22 @@ def test_host_mirror_matches_reference_behaviour(oracle):
     ref, _ = oracle.deflate_spliced(data, np.array([0, 0, 65536, 65636], np.uint64))
     assert bytes.fromhex(lines["one"]) == ref
     assert lines["unspliced"] == "none 65636 0"
+    # BatchWriter: same bytes per stream as lone Writers, sticky state per Writer
+    assert lines["bw_close"] == "none" and lines["bw_close2"] == "none"
+    assert bytes.fromhex(lines["bw0"]) == want
+    assert bytes.fromhex(lines["bw1"]) == oracle.deflate(ramp)
+    assert bytes.fromhex(lines["bw2"]) == bytes([1, 0, 0, 0xFF, 0xFF])
+    assert lines["bw_write_after_close"] == "0 writer closed"
+    # chunked Writer: one spliced stream of independent 65536-byte chunks = the oracle's spliced
+    # compressor over the same cut; any inflater (zlib here) returns the input
+    import zlib
+    x, big = 12345, bytearray()
+    for _ in range(300000):
+        x = (x * 1664525 + 1013904223) & 0xFFFFFFFF
+        big.append(b"etaoin shrdlu"[(x >> 24) % 13])
+    cuts = np.array([0, 65536, 131072, 196608, 262144, 300000], np.uint64)
+    ref, _ = oracle.deflate_spliced(np.frombuffer(bytes(big), np.uint8), cuts)
+    got = bytes.fromhex(lines["chunked_bytes"])
+    assert lines["chunked"] == "none %d" % len(ref) and got == ref
+    assert zlib.decompressobj(-15).decompress(got) == bytes(big)
+    assert lines["chunked_back"] == "300000 EOF 0"

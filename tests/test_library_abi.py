@@ -96,5 +96,16 @@ def test_moonbit_stub_compiles_and_links_against_the_library(lib, tmp_path):
                            "-o", str(so)])
     import ctypes
     stub = ctypes.CDLL(str(so))
-    for name in ("flate_hip_mbt_ctx_new", "flate_hip_mbt_deflate_batch", "flate_hip_mbt_inflate_batch"):
+    for name in ("flate_hip_mbt_ctx_new", "flate_hip_mbt_ctx_is_null", "flate_hip_mbt_deflate_batch",
+                 "flate_hip_mbt_inflate_batch", "flate_hip_mbt_deflate_spliced"):
         assert hasattr(stub, name)
+    # every symbol the .mbt binding names in an `extern "C" fn ... = "sym"` exists in the stub or
+    # in the library, and the binding never copies a buffer on its way to C
+    import re
+    mbt = open(os.path.join(root, "integration", "moonbit", "flate_hip_native.mbt")).read()
+    code = "\n".join(ln for ln in mbt.splitlines() if not ln.lstrip().startswith("//"))
+    syms = re.findall(r'\)\s*->\s*\w+\s*=\s*"(\w+)"', code)
+    assert len(syms) >= 7
+    for name in syms:
+        assert hasattr(stub, name) or hasattr(lib, name), name
+    assert "from_fixedarray" not in code
