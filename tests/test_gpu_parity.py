@@ -205,3 +205,28 @@ def test_full_size_config3_multi_window(eng, oracle):
     c = comp[:int(coff[-1])].cpu().numpy()
     for i in range(0, n, 61):
         assert bytes(c[int(coff[i]):int(coff[i + 1])]) == oracle.deflate(host[i * blen:(i + 1) * blen]), i
+
+
+def test_full_size_config3_default_geometry(oracle):
+    # BASELINE configs[2] at FULL size with the DEFAULT launch geometry: 4096 x 256 KiB streams is at
+    # guest_min_streams, so the persistent resident + guest MULTI kernels (shared queue, swept 16-bit
+    # tables) are what runs.  Both compat modes; byte-exact against the oracle on a strided sample,
+    # and every stream round-trips through the GPU inflater.
+    import torch
+    n, blen = 4096, 262144
+    host = flate.synth("text", n, blen)
+    off = flate.uniform_offsets(n, blen)
+    d = torch.from_numpy(host).cuda()
+    e = flate.FlateEngine(0)   # fresh engine: default options
+    try:
+        for go in (False, True):
+            comp, coff = e.deflate_batch(d, off, out_cap=n * blen, compat_go=go)
+            back, _, olen, status, _ = e.inflate_batch(comp, coff, [blen] * n)
+            assert (status == 0).all() and (olen == blen).all() and torch.equal(back[:n * blen], d)
+            c = comp[:int(coff[-1])].cpu().numpy()
+            for i in range(0, n, 127):
+                want = oracle.deflate(host[i * blen:(i + 1) * blen], compat=oracle.COMPAT_GO if go else 0)
+                assert bytes(c[int(coff[i]):int(coff[i + 1])]) == want, (go, i)
+            del comp, back
+    finally:
+        e.close()
