@@ -11,11 +11,13 @@ __global__ __launch_bounds__(1024) void scan_sizes_kernel(CompactParams P) {
   __shared__ uint64_t wtot[16];
   __shared__ uint64_t carry_s;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  if (tid == 0) carry_s = 0;
+  const uint32_t lo = P.carry ? P.first : 0u;
+  const uint32_t hi = P.carry ? P.first + P.count : P.n_streams;
+  if (tid == 0) carry_s = P.carry ? *P.carry : 0ull;
   __syncthreads();
-  for (uint32_t base = 0; base < P.n_streams; base += 1024) {
+  for (uint32_t base = lo; base < hi; base += 1024) {
     const uint32_t i = base + (uint32_t)tid;
-    const uint64_t v = i < P.n_streams ? P.out_len[i] : 0ull;
+    const uint64_t v = i < hi ? P.out_len[i] : 0ull;
     uint64_t x = v;
     for (int d = 1; d < 64; d <<= 1) {
       const uint64_t o = __shfl_up(x, d);
@@ -26,15 +28,34 @@ __global__ __launch_bounds__(1024) void scan_sizes_kernel(CompactParams P) {
     uint64_t woff = 0;
     for (int w = 0; w < wid; ++w) woff += wtot[w];
     const uint64_t carry = carry_s;
-    if (i < P.n_streams) P.out_off[i] = carry + woff + x - v;
+    if (i < hi) P.out_off[i] = carry + woff + x - v;
     __syncthreads();
     if (tid == 1023) carry_s = carry + woff + x;
     __syncthreads();
   }
   if (tid == 0) {
-    P.out_off[P.n_streams] = carry_s;
+    if (P.carry) *P.carry = carry_s;
+    if (hi == P.n_streams) P.out_off[P.n_streams] = carry_s;
     if (carry_s > P.out_cap) *P.status = -2;  // FLATE_HIP_E_OUT_TOO_SMALL
   }
+}
+
+// Gate of a sub-batch of the entropy stage: the match finder (still running on other HIP streams)
+// counts the streams of the sub-batch it has finished; this one-lane kernel returns when all of
+// them are there.  The spin is bounded (about 4 s of the 100 MHz real-time counter): a count that
+// never arrives becomes an error code, not a hang.
+__global__ void wait_count_kernel(const uint32_t *counter, uint32_t target, int *status) {
+  const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+  for (;;) {
+    const uint32_t v = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v >= target) break;
+    if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) {
+      atomicExch(status, -8);  // FLATE_HIP_E_INTERNAL
+      break;
+    }
+    __builtin_amdgcn_s_sleep(32);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
 }  // namespace flate

@@ -56,6 +56,19 @@ struct flate_hip_ctx {
   // tools/inflate_crossover.py)
   uint32_t inflate_simt_min = 2049;
   uint32_t resident_blocks = 1280;  // persistent LDS-table blocks (5 per CU x 256 CUs)
+  // Entropy stage overlapped with the match finder: the batch is cut into overlap_sub sub-batches
+  // (queue order); hist/code/scan/pack of a sub-batch run on ent_stream as soon as the match finder
+  // -- one launch over the whole batch -- has counted all of its streams done.  0 = off (default:
+  // measured slower on MI355X, profiles/r02/README.md -- the entropy kernels run 3x slower beside
+  // the match finder than after it, so nothing is gained).
+  int overlap_sub = 0;
+  uint32_t overlap_resident = 1024;  // LDS-table blocks while overlapping (4 per CU: leaves 32 KiB
+                                     // of LDS per CU to the entropy kernels)
+  hipStream_t ent_stream = nullptr;
+  hipEvent_t ev_ent = nullptr;
+  std::vector<hipEvent_t> ent_ev;    // profiling: start/end of every sub-batch's entropy kernels
+  DevBuf d_done;                     // overlap_sub counters + the running output size (u64)
+  bool overlapped = false;           // what the last encode call did
   int lz_team = 0;                  // 1: two wavefronts per stream (lz77_team_kernels.hip)
   int lz_pipe = 0;                  // 1: pipelined one-wave kernels (lz77_pipe_kernels.hip)
   uint32_t team_resident = 1024;    // persistent LDS-table teams (4 per CU: 32 KiB + token each)
@@ -169,8 +182,10 @@ int collect_timing(flate_hip_ctx *c, const bool used[FLATE_HIP_STAGE_COUNT]) {
 }
 
 // Upload the index arrays and run the match finder over every LZ77 chunk.
+// overlap_sub > 0: count finished streams per sub-batch of that many queue entries in c->d_done
+// (the caller has checked that the launch is one persistent resident+guest launch in stream order)
 int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, const StagePlan &pl,
-             uint32_t flags) {
+             uint32_t flags, uint32_t overlap_sub = 0) {
   const uint32_t n = pl.n_streams;
   int rc;
   if ((rc = ensure(c, c->d_in_off, ((size_t)n + 1) * 8))) return rc;
@@ -207,6 +222,9 @@ int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, cons
   P.gtables = nullptr;
   P.queue = nullptr;
   P.queue_end = 0;
+  P.done = overlap_sub ? (uint32_t *)c->d_done.p : nullptr;
+  P.done_shift = 0;
+  while (overlap_sub && (1u << P.done_shift) < overlap_sub) ++P.done_shift;  // (a power of two)
   if (c->guest_blocks > 0 || c->lz_team) {
     const size_t gt = c->lz_team ? (size_t)c->team_guests : (size_t)c->guest_blocks;
     if ((rc = ensure(c, c->d_gtables, gt * kTableSize * 2 + 64))) return rc;
@@ -292,7 +310,8 @@ int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, cons
         G.queue_end = count;
         (void)hipEventRecord(c->ev_fork, c->stream);
         (void)hipStreamWaitEvent(c->guest_stream, c->ev_fork, 0);
-        const uint32_t resident = c->resident_blocks < count ? c->resident_blocks : count;
+        uint32_t resident = c->resident_blocks < count ? c->resident_blocks : count;
+        if (overlap_sub && c->overlap_resident < resident) resident = c->overlap_resident;
         if (pipe && multi) {
           hipLaunchKernelGGL(lz77_pipe_guest_kernel<true>, dim3((uint32_t)c->guest_blocks), dim3(64), 0,
                              c->guest_stream, G);
@@ -370,7 +389,11 @@ int flate_hip_init(int device, flate_hip_ctx **out) {
     return FLATE_HIP_E_NO_DEVICE;
   }
   c->stream = c->own_stream;
-  if (hipStreamCreateWithFlags(&c->guest_stream, hipStreamNonBlocking) != hipSuccess ||
+  int prio_lo = 0, prio_hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+  if (hipStreamCreateWithPriority(&c->ent_stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_ent, hipEventDisableTiming) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->guest_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
     flate_hip_destroy(c);
@@ -384,6 +407,7 @@ int flate_hip_init(int device, flate_hip_ctx **out) {
     c->num_cus = (uint32_t)cus;
     c->resident_blocks = 5u * (uint32_t)cus;
     c->guest_blocks = 5 * cus;
+    c->overlap_resident = 4u * (uint32_t)cus;
     c->team_resident = 4u * (uint32_t)cus;
     c->team_guests = 5u * (uint32_t)cus;
   }
@@ -421,6 +445,11 @@ void flate_hip_destroy(flate_hip_ctx *c) {
   for (auto &e : c->ev)
     if (e) (void)hipEventDestroy(e);
   if (c->guest_stream) (void)hipStreamDestroy(c->guest_stream);
+  if (c->ent_stream) (void)hipStreamDestroy(c->ent_stream);
+  if (c->ev_ent) (void)hipEventDestroy(c->ev_ent);
+  for (auto &e : c->ent_ev)
+    if (e) (void)hipEventDestroy(e);
+  release(c->d_done);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -446,6 +475,10 @@ int flate_hip_set_option(flate_hip_ctx *c, const char *name, int64_t value) {
     c->inflate_simt_min = (uint32_t)value;
   } else if (k == "resident_blocks" && value > 0 && value <= 65536) {
     c->resident_blocks = (uint32_t)value;
+  } else if (k == "overlap_sub_batches" && value >= 0 && value <= 64) {
+    c->overlap_sub = (int)value;
+  } else if (k == "overlap_resident_blocks" && value > 0 && value <= 65536) {
+    c->overlap_resident = (uint32_t)value;
   } else if (k == "lz_team" && (value == 0 || value == 1)) {
     c->lz_team = (int)value;
   } else if (k == "lz_pipe" && (value == 0 || value == 1)) {
@@ -502,8 +535,6 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
     d_in = (const uint8_t *)c->d_in.p;
     d_out = (uint8_t *)c->d_out.p;
   }
-  if ((rc = run_lz77(c, d_in, in_off, pl, flags))) return rc;
-
   const size_t nb = (size_t)pl.n_blocks + 1;
   if ((rc = ensure(c, c->d_blk_base, ((size_t)n + 1) * 4))) return rc;
   if ((rc = ensure(c, c->d_blk_hist, nb * 320 * 4))) return rc;
@@ -518,6 +549,36 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
   HIP_TRY(c, hipMemcpyAsync(c->d_blk_base.p, pl.blk_base.data(), ((size_t)n + 1) * 4,
                             hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemsetAsync(c->d_status.p, 0, 4, c->stream));
+
+  // Overlap (see flate_hip_ctx::overlap_sub): possible when the match finder is ONE persistent
+  // resident+guest launch whose queue is the stream order (every stream has LZ77 chunks and all are
+  // of one kind), the output is not spliced (the splice needs every stream's size first) and the
+  // one-wave kernels run (the experimental team kernels do not count their streams).
+  const uint32_t list = (uint32_t)(pl.ids16.size() == n ? n : (pl.ids32.size() == n ? n : 0));
+  const bool overlap = c->overlap_sub > 0 && !spliced && list == n && n >= c->guest_min &&
+                       c->guest_blocks > 0 && !c->lz_team && !c->lz_pipe && !(flags & FLATE_HIP_LZ_SERIAL) &&
+                       n >= 4u * (uint32_t)c->overlap_sub;
+  c->overlapped = overlap;
+  // sub-batch size: the power of two that gives at most overlap_sub sub-batches
+  uint32_t sub = n;
+  if (overlap) {
+    sub = 1;
+    while ((uint64_t)sub * (uint32_t)c->overlap_sub < n) sub <<= 1;
+  }
+  const uint32_t J = overlap ? (n + sub - 1) / sub : 1u;
+  if (overlap) {
+    if ((rc = ensure(c, c->d_done, 64 * 4 + 16))) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->d_done.p, 0, 64 * 4 + 16, c->stream));
+    while (c->ent_ev.size() < 2 * (size_t)J) {
+      hipEvent_t e = nullptr;
+      HIP_TRY(c, hipEventCreate(&e));
+      c->ent_ev.push_back(e);
+    }
+  }
+  if ((rc = run_lz77(c, d_in, in_off, pl, flags, overlap ? sub : 0u))) return rc;
+  // ev_fork sits on c->stream right in front of the match finder's launch, behind every upload
+  // and memset the entropy kernels depend on
+  if (overlap) (void)hipStreamWaitEvent(c->ent_stream, c->ev_fork, 0);
 
   HuffParams H;
   H.in = d_in;
@@ -540,13 +601,41 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
   H.status = (int *)c->d_status.p;
   H.n_streams = n;
   H.compat_go = (flags & FLATE_HIP_COMPAT_GO) ? 1u : 0u;
+  H.sid0 = 0;
+  H.prio = overlap ? 1u : 0u;
   CompactParams C;
   C.out_len = (const uint64_t *)c->d_out_len.p;
   C.out_off = (uint64_t *)c->d_out_off.p;
   C.out_cap = out_cap;
   C.n_streams = n;
   C.status = (int *)c->d_status.p;
-  {
+  C.first = 0;
+  C.count = n;
+  C.carry = nullptr;
+  if (overlap) {
+    // the sub-batches in queue order on ent_stream, each behind its gate; the match finder keeps
+    // running on c->stream / guest_stream
+    uint32_t *done = (uint32_t *)c->d_done.p;
+    C.carry = (uint64_t *)((uint8_t *)c->d_done.p + 64 * 4);
+    for (uint32_t j = 0; j < J; ++j) {
+      const uint32_t first = j * sub;
+      if (first >= n) break;
+      const uint32_t cnt = n - first < sub ? n - first : sub;
+      hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(1), 0, c->ent_stream, done + j, cnt,
+                         (int *)c->d_status.p);
+      if (c->profiling) (void)hipEventRecord(c->ent_ev[2 * j], c->ent_stream);
+      H.sid0 = first;
+      C.first = first;
+      C.count = cnt;
+      hipLaunchKernelGGL(huff_hist_kernel, dim3(cnt), dim3(64), 0, c->ent_stream, H);
+      hipLaunchKernelGGL(huff_code_kernel, dim3(cnt), dim3(64), 0, c->ent_stream, H);
+      hipLaunchKernelGGL(scan_sizes_kernel, dim3(1), dim3(1024), 0, c->ent_stream, C);
+      hipLaunchKernelGGL(huff_pack_kernel, dim3(cnt), dim3(64), 0, c->ent_stream, H);
+      if (c->profiling) (void)hipEventRecord(c->ent_ev[2 * j + 1], c->ent_stream);
+    }
+    (void)hipEventRecord(c->ev_ent, c->ent_stream);
+    (void)hipStreamWaitEvent(c->stream, c->ev_ent, 0);
+  } else {
     StageTimer t(c, FLATE_HIP_STAGE_HUFF_PACK);
     hipLaunchKernelGGL(huff_hist_kernel, dim3(n), dim3(64), 0, c->stream, H);
     hipLaunchKernelGGL(huff_code_kernel, dim3(n), dim3(64), 0, c->stream, H);
@@ -589,6 +678,23 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
   if (!dev) {
     HIP_TRY(c, hipMemcpyAsync(out, c->d_out.p, produced, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  if (c->overlapped) {
+    // huff_pack = the time the entropy kernels were busy (sum over the sub-batches, gate waits
+    // excluded); it runs beside lz77_match, so the two no longer add up to the step
+    const bool used[FLATE_HIP_STAGE_COUNT] = {true, false, false, false};
+    if ((rc = collect_timing(c, used))) return rc;
+    if (c->profiling) {
+      float tot = 0.f;
+      const uint32_t Jn = (n + sub - 1) / sub;
+      for (uint32_t j = 0; j < Jn; ++j) {
+        float ms = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ent_ev[2 * j], c->ent_ev[2 * j + 1]));
+        tot += ms;
+      }
+      c->stage_ms[FLATE_HIP_STAGE_HUFF_PACK] = tot;
+    }
+    return FLATE_HIP_OK;
   }
   const bool used[FLATE_HIP_STAGE_COUNT] = {true, true, false, false};
   return collect_timing(c, used);

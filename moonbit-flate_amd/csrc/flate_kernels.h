@@ -25,6 +25,10 @@ struct LzParams {
   void *gtables;        // one table per guest block
   uint32_t *queue;      // next index into stream_ids
   uint32_t queue_end;
+  // overlap with the entropy stage: done[q >> done_shift] counts the finished streams of every
+  // sub-batch of the queue (null = off); incremented after the stream's records are visible
+  uint32_t *done;
+  uint32_t done_shift;
 };
 
 // Entropy stage.  Blocks are the units enc_speed writes: every full 65535-byte window plus the
@@ -52,6 +56,8 @@ struct HuffParams {
   int *status;
   uint32_t n_streams;
   uint32_t compat_go;
+  uint32_t sid0;  // first stream of this launch (sub-batched launches; block b handles sid0 + b)
+  uint32_t prio;  // 1: raise the wave priority (the launch runs beside the match finder)
 };
 
 struct CompactParams {
@@ -60,6 +66,11 @@ struct CompactParams {
   uint64_t out_cap;
   uint32_t n_streams;
   int *status;  // set to FLATE_HIP_E_OUT_TOO_SMALL if the total exceeds out_cap
+  // sub-batched scan: streams [first, first + count) continue from *carry (device; the bytes of
+  // all earlier streams) and leave the new total there; the launch that reaches n_streams also
+  // writes out_off[n_streams] and checks out_cap.  carry == null: one launch over everything.
+  uint32_t first, count;
+  uint64_t *carry;
 };
 
 struct InfParams {
@@ -97,6 +108,9 @@ __global__ void huff_hist_kernel(HuffParams P);
 __global__ void huff_code_kernel(HuffParams P);
 __global__ void huff_pack_kernel(HuffParams P);
 __global__ void scan_sizes_kernel(CompactParams P);
+// spins (bounded) until *counter >= target: gates a sub-batch of the entropy stage on the match
+// finder that is still running on another stream
+__global__ void wait_count_kernel(const uint32_t *counter, uint32_t target, int *status);
 __global__ void inflate_kernel(InfParams P);
 template <int LPW>
 __global__ void inflate_simt_kernel(InfParams P);

@@ -636,6 +636,16 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
   }
 }
 
+// Overlap with the entropy stage (flate_api.hip): queue entry q is finished -- make its match
+// records and counts visible device-wide, then count it in its sub-batch.
+FLATE_D void stream_done(const LzParams &P, uint32_t q, int lane) {
+  if (!P.done) return;
+  // (the release covers the whole wavefront's stores: the wait the compiler emits in front of the
+  // L2 write-back is the wave's vmcnt, and a wave barrier precedes this call)
+  if (lane == 0)
+    __hip_atomic_fetch_add(P.done + (q >> P.done_shift), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Resident kernel: table in LDS (32 KiB per stream => 5 streams per CU).
 template <bool MULTI>
 __global__ __launch_bounds__(64) void lz77_wave_kernel(LzParams P) {
@@ -657,6 +667,7 @@ __global__ __launch_bounds__(64) void lz77_wave_kernel(LzParams P) {
     __syncthreads();
     lz77_stream<MULTI>(P, P.stream_ids ? P.stream_ids[q] : q, table, lane);
     __syncthreads();
+    stream_done(P, q, lane);
   }
 }
 
@@ -676,6 +687,7 @@ __global__ __launch_bounds__(64) void lz77_guest_kernel(LzParams P) {
     __syncthreads();
     lz77_stream<MULTI, true>(P, P.stream_ids[q], table, lane);
     __syncthreads();
+    stream_done(P, q, lane);
   }
 }
 

@@ -230,3 +230,25 @@ def test_full_size_config3_default_geometry(oracle):
             del comp, back
     finally:
         e.close()
+
+
+def test_overlapped_entropy_stage_is_bit_exact(oracle):
+    # option "overlap_sub_batches": hist/code/scan/pack of a sub-batch run on a second HIP stream as
+    # soon as the match finder (one launch over the whole batch) has counted its streams done.
+    # Off by default (measured slower); the results must not depend on it.
+    n = 1024
+    data = flate.synth("text", n, 65536)
+    off = flate.uniform_offsets(n, 65536)
+    want, w_off, w_len = oracle.deflate_batch(data, off, nthreads=8)
+    e = flate.FlateEngine(0)
+    try:
+        e.set_option("guest_min_streams", 1)
+        for sub in (1, 4, 8, 64):
+            e.set_option("overlap_sub_batches", sub)
+            out, out_off = e.deflate_batch(data, off)
+            for i in range(n):
+                a = out[int(out_off[i]):int(out_off[i + 1])]
+                b = want[int(w_off[i]):int(w_off[i]) + int(w_len[i])]
+                assert a.size == b.size and np.array_equal(a, b), (sub, i)
+    finally:
+        e.close()
