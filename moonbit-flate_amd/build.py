@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libflate_hip.so")
 
-SOURCES = ["lz77_kernels.hip", "lz77_team_kernels.hip", "lz77_pipe_kernels.hip", "huff_pack_kernels.hip", "compact_kernels.hip",
+SOURCES = ["lz77_kernels.hip",  "huff_pack_kernels.hip", "compact_kernels.hip",
            "inflate_kernels.hip", "splice_kernels.hip", "flate_api.hip", "synth.cpp"]
 HEADERS = ["flate_common.h", "flate_kernels.h", "lz77_device.h", os.path.join(ROOT, "include", "flate_hip.h")]
 

@@ -69,10 +69,6 @@ struct flate_hip_ctx {
   std::vector<hipEvent_t> ent_ev;    // profiling: start/end of every sub-batch's entropy kernels
   DevBuf d_done;                     // overlap_sub counters + the running output size (u64)
   bool overlapped = false;           // what the last encode call did
-  int lz_team = 0;                  // 1: two wavefronts per stream (lz77_team_kernels.hip)
-  int lz_pipe = 0;                  // 1: pipelined one-wave kernels (lz77_pipe_kernels.hip)
-  uint32_t team_resident = 1024;    // persistent LDS-table teams (4 per CU: 32 KiB + token each)
-  uint32_t team_guests = 1280;      // persistent L2-table teams
   uint32_t queue_init = 0;
   uint32_t debug_chunks = 0;
 };
@@ -225,9 +221,8 @@ int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, cons
   P.done = overlap_sub ? (uint32_t *)c->d_done.p : nullptr;
   P.done_shift = 0;
   while (overlap_sub && (1u << P.done_shift) < overlap_sub) ++P.done_shift;  // (a power of two)
-  if (c->guest_blocks > 0 || c->lz_team) {
-    const size_t gt = c->lz_team ? (size_t)c->team_guests : (size_t)c->guest_blocks;
-    if ((rc = ensure(c, c->d_gtables, gt * kTableSize * 2 + 64))) return rc;
+  if (c->guest_blocks > 0) {
+    if ((rc = ensure(c, c->d_gtables, (size_t)c->guest_blocks * kTableSize * 2 + 64))) return rc;
     if ((rc = ensure(c, c->d_queue, 64))) return rc;
     const uint32_t n16 = (uint32_t)pl.ids16.size();
     (void)n16;
@@ -258,46 +253,9 @@ int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, cons
       auto launch = [&](const DevBuf &ids, uint32_t count, bool multi, uint32_t queue_slot) {
         if (!count) return;
         P.stream_ids = (const uint32_t *)ids.p;
-        if (c->lz_team) {
-          const bool persistent = count >= c->guest_min;
-          LzParams G = P;
-          if (!persistent) {
-            if (multi)
-              hipLaunchKernelGGL(lz77_team_kernel<true>, dim3(count), dim3(128), 0, c->stream, G);
-            else
-              hipLaunchKernelGGL(lz77_team_kernel<false>, dim3(count), dim3(128), 0, c->stream, G);
-            return;
-          }
-          G.gtables = c->d_gtables.p;
-          G.queue = (uint32_t *)c->d_queue.p + queue_slot;
-          G.queue_end = count;
-          const uint32_t resident = c->team_resident < count ? c->team_resident : count;
-          const bool guests = c->team_guests > 0;
-          if (guests) {
-            (void)hipEventRecord(c->ev_fork, c->stream);
-            (void)hipStreamWaitEvent(c->guest_stream, c->ev_fork, 0);
-            if (multi)
-              hipLaunchKernelGGL(lz77_team_guest_kernel<true>, dim3(c->team_guests), dim3(128), 0, c->guest_stream, G);
-            else
-              hipLaunchKernelGGL(lz77_team_guest_kernel<false>, dim3(c->team_guests), dim3(128), 0, c->guest_stream, G);
-            (void)hipEventRecord(c->ev_join, c->guest_stream);
-          }
-          if (multi)
-            hipLaunchKernelGGL(lz77_team_kernel<true>, dim3(resident), dim3(128), 0, c->stream, G);
-          else
-            hipLaunchKernelGGL(lz77_team_kernel<false>, dim3(resident), dim3(128), 0, c->stream, G);
-          if (guests) (void)hipStreamWaitEvent(c->stream, c->ev_join, 0);
-          return;
-        }
         const bool guests = c->guest_blocks > 0 && count >= c->guest_min;
-        const bool pipe = c->lz_pipe != 0;
         if (!guests) {
-          if (pipe) {
-            if (multi)
-              hipLaunchKernelGGL(lz77_pipe_kernel<true>, dim3(count), dim3(64), 0, c->stream, P);
-            else
-              hipLaunchKernelGGL(lz77_pipe_kernel<false>, dim3(count), dim3(64), 0, c->stream, P);
-          } else if (multi)
+          if (multi)
             hipLaunchKernelGGL(lz77_wave_kernel<true>, dim3(count), dim3(64), 0, c->stream, P);
           else
             hipLaunchKernelGGL(lz77_wave_kernel<false>, dim3(count), dim3(64), 0, c->stream, P);
@@ -312,17 +270,7 @@ int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, cons
         (void)hipStreamWaitEvent(c->guest_stream, c->ev_fork, 0);
         uint32_t resident = c->resident_blocks < count ? c->resident_blocks : count;
         if (overlap_sub && c->overlap_resident < resident) resident = c->overlap_resident;
-        if (pipe && multi) {
-          hipLaunchKernelGGL(lz77_pipe_guest_kernel<true>, dim3((uint32_t)c->guest_blocks), dim3(64), 0,
-                             c->guest_stream, G);
-          (void)hipEventRecord(c->ev_join, c->guest_stream);
-          hipLaunchKernelGGL(lz77_pipe_kernel<true>, dim3(resident), dim3(64), 0, c->stream, G);
-        } else if (pipe) {
-          hipLaunchKernelGGL(lz77_pipe_guest_kernel<false>, dim3((uint32_t)c->guest_blocks), dim3(64), 0,
-                             c->guest_stream, G);
-          (void)hipEventRecord(c->ev_join, c->guest_stream);
-          hipLaunchKernelGGL(lz77_pipe_kernel<false>, dim3(resident), dim3(64), 0, c->stream, G);
-        } else if (multi) {
+        if (multi) {
           hipLaunchKernelGGL(lz77_guest_kernel<true>, dim3((uint32_t)c->guest_blocks), dim3(64), 0,
                              c->guest_stream, G);
           (void)hipEventRecord(c->ev_join, c->guest_stream);
@@ -408,12 +356,8 @@ int flate_hip_init(int device, flate_hip_ctx **out) {
     c->resident_blocks = 5u * (uint32_t)cus;
     c->guest_blocks = 5 * cus;
     c->overlap_resident = 4u * (uint32_t)cus;
-    c->team_resident = 4u * (uint32_t)cus;
-    c->team_guests = 5u * (uint32_t)cus;
   }
   if (const char *e = getenv("FLATE_HIP_GUEST_BLOCKS")) c->guest_blocks = atoi(e) < 0 ? 0 : atoi(e);
-  if (const char *e = getenv("FLATE_HIP_LZ_TEAM")) c->lz_team = atoi(e) != 0;
-  if (const char *e = getenv("FLATE_HIP_LZ_PIPE")) c->lz_pipe = atoi(e) != 0;
   if (const char *e = getenv("FLATE_HIP_GUEST_MIN")) c->guest_min = (uint32_t)atoi(e);
   if (const char *e = getenv("FLATE_HIP_RESIDENT_BLOCKS")) c->resident_blocks = atoi(e) < 1 ? 1u : (uint32_t)atoi(e);
   for (auto &e : c->ev)
@@ -479,14 +423,7 @@ int flate_hip_set_option(flate_hip_ctx *c, const char *name, int64_t value) {
     c->overlap_sub = (int)value;
   } else if (k == "overlap_resident_blocks" && value > 0 && value <= 65536) {
     c->overlap_resident = (uint32_t)value;
-  } else if (k == "lz_team" && (value == 0 || value == 1)) {
-    c->lz_team = (int)value;
-  } else if (k == "lz_pipe" && (value == 0 || value == 1)) {
-    c->lz_pipe = (int)value;
-  } else if (k == "team_resident_blocks" && value > 0 && value <= 65536) {
-    c->team_resident = (uint32_t)value;
-  } else if (k == "team_guest_blocks" && value >= 0 && value <= 65536) {
-    c->team_guests = (uint32_t)value;
+
   } else {
     return FLATE_HIP_E_INVALID;
   }
@@ -553,10 +490,10 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
   // Overlap (see flate_hip_ctx::overlap_sub): possible when the match finder is ONE persistent
   // resident+guest launch whose queue is the stream order (every stream has LZ77 chunks and all are
   // of one kind), the output is not spliced (the splice needs every stream's size first) and the
-  // one-wave kernels run (the experimental team kernels do not count their streams).
+  // wave kernels run (the single-lane debug kernel does not count its streams).
   const uint32_t list = (uint32_t)(pl.ids16.size() == n ? n : (pl.ids32.size() == n ? n : 0));
   const bool overlap = c->overlap_sub > 0 && !spliced && list == n && n >= c->guest_min &&
-                       c->guest_blocks > 0 && !c->lz_team && !c->lz_pipe && !(flags & FLATE_HIP_LZ_SERIAL) &&
+                       c->guest_blocks > 0 && !(flags & FLATE_HIP_LZ_SERIAL) &&
                        n >= 4u * (uint32_t)c->overlap_sub;
   c->overlapped = overlap;
   // sub-batch size: the power of two that gives at most overlap_sub sub-batches

@@ -94,16 +94,6 @@ template <bool MULTI>
 __global__ void lz77_wave_kernel(LzParams P);
 template <bool MULTI>
 __global__ void lz77_guest_kernel(LzParams P);
-// two wavefronts per stream (lz77_team_kernels.hip): LDS-table teams and L2-table guest teams
-template <bool MULTI>
-__global__ void lz77_team_kernel(LzParams P);
-template <bool MULTI>
-__global__ void lz77_team_guest_kernel(LzParams P);
-// one wavefront per stream, next batch's front end issued ahead (lz77_pipe_kernels.hip)
-template <bool MULTI>
-__global__ void lz77_pipe_kernel(LzParams P);
-template <bool MULTI>
-__global__ void lz77_pipe_guest_kernel(LzParams P);
 __global__ void huff_hist_kernel(HuffParams P);
 __global__ void huff_code_kernel(HuffParams P);
 __global__ void huff_pack_kernel(HuffParams P);
