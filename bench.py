@@ -337,6 +337,11 @@ def bench_deflate(args, env, host, d_in, in_off, n, blen):
     clen = int(out_off[-1])
     ratio = in_bytes / clen
     steps = args.steps
+    split = None
+    if hasattr(eng, "last_resident_share"):
+        a, b = eng.last_resident_share()
+        if b:
+            split = {"lds_table_blocks": a, "l2_table_guest_blocks": b - a, "queued": b}
 
     # exchange step alone, both forms (outside the timed region; N>1)
     gather_info = "none"
@@ -422,6 +427,7 @@ def bench_deflate(args, env, host, d_in, in_off, n, blen):
             "parity_checked_streams": verified,
             "stage_ms": {k: round(v / steps, 3) for k, v in stage_ms.items()},
             "step_ms": summarize(step_s),
+            "lz77_streams_by_kernel": split,
         },
         "roofline": {
             "bound": "hbm", "kernel": "lz77 match finder (resident + guest launch)", "achieved": round(achieved, 2),

@@ -64,6 +64,9 @@ int flate_hip_set_stream(flate_hip_ctx *ctx, void *hip_stream);
  *                        (default 5 per CU; 0 = off)
  *   "resident_blocks"    persistent LDS-table wavefronts (default 5 per CU)
  *   "guest_min_streams"  batches smaller than this use one block per stream (default 4096)
+ *   "overlap_sub_batches"  > 0: the entropy kernels of every sub-batch (queue order) run on a
+ *                        second HIP stream as soon as the match finder has counted its streams
+ *                        done (default 0: measured slower on MI355X)
  *   "inflate_simt_min_streams"  inflate batches at least this large decode one stream per LANE
  *                        (64 per wavefront) instead of one per wavefront (default 2049)
  *   "inflate_lanes"      streams per wavefront of that decoder: 0 = chosen from the batch size
@@ -150,6 +153,14 @@ int flate_hip_deflate_fast_spliced(flate_hip_ctx *ctx, const uint8_t *in,
 #define FLATE_HIP_STAGE_INFLATE 3
 #define FLATE_HIP_STAGE_COUNT 4
 int flate_hip_set_profiling(flate_hip_ctx *ctx, int on);
+/* How the last encode call's persistent match-finder launch split its stream queue:
+ * *resident_streams taken by the LDS-table blocks out of *queued_streams (the rest went to the
+ * L2-table guest blocks); both 0 if the launch was not persistent.  With the option
+ * "profile_split_streams" = K the split is fixed (first K queue entries to the LDS-table blocks)
+ * instead of dynamic: a profiler that serialises the two kernels (rocprofv3 --pmc) then still
+ * sees each of them do its share -- how profiles/r02/lz77_traffic.json was collected. */
+int flate_hip_last_resident_share(flate_hip_ctx *ctx, uint32_t *resident_streams,
+                                  uint32_t *queued_streams);
 int flate_hip_last_timing(flate_hip_ctx *ctx, float *ms, int n);
 const char *flate_hip_stage_name(int stage);
 

@@ -12,7 +12,7 @@ EXPORTS = [
     "flate_hip_strerror",
     "flate_hip_last_hip_error", "flate_hip_deflate_bound", "flate_hip_deflate_fast_batch",
     "flate_hip_lz77_matches", "flate_hip_inflate_batch", "flate_hip_deflate_fast_spliced",
-    "flate_hip_inflate_spliced", "flate_hip_set_profiling",
+    "flate_hip_inflate_spliced", "flate_hip_set_profiling", "flate_hip_last_resident_share",
     "flate_hip_last_timing", "flate_hip_stage_name", "flate_hip_synth_fill",
 ]
 
@@ -61,6 +61,8 @@ def load():
     L.flate_hip_inflate_spliced.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, vp, vp, vp, vp, vp, C.c_uint32]
     L.flate_hip_inflate_spliced.restype = C.c_int
     L.flate_hip_set_profiling.argtypes = [vp, C.c_int]
+    L.flate_hip_last_resident_share.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.flate_hip_last_resident_share.restype = C.c_int
     L.flate_hip_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
     L.flate_hip_stage_name.argtypes = [C.c_int]
     L.flate_hip_stage_name.restype = C.c_char_p

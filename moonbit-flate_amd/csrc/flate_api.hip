@@ -69,6 +69,10 @@ struct flate_hip_ctx {
   std::vector<hipEvent_t> ent_ev;    // profiling: start/end of every sub-batch's entropy kernels
   DevBuf d_done;                     // overlap_sub counters + the running output size (u64)
   bool overlapped = false;           // what the last encode call did
+  // measurement aids (flate_hip_last_resident_share, option "profile_split_streams")
+  uint32_t profile_split = 0;        // > 0: LDS-table blocks take exactly the first K queue entries,
+                                     // the guest blocks the rest (two queues instead of one)
+  uint32_t last_count[2] = {0, 0};   // queue lengths of the last persistent launches (16-bit, multi)
   uint32_t queue_init = 0;
   uint32_t debug_chunks = 0;
 };
@@ -219,6 +223,8 @@ int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, cons
   P.queue = nullptr;
   P.queue_end = 0;
   P.done = overlap_sub ? (uint32_t *)c->d_done.p : nullptr;
+  P.taken = nullptr;
+  c->last_count[0] = c->last_count[1] = 0;
   P.done_shift = 0;
   while (overlap_sub && (1u << P.done_shift) < overlap_sub) ++P.done_shift;  // (a power of two)
   if (c->guest_blocks > 0) {
@@ -226,7 +232,7 @@ int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, cons
     if ((rc = ensure(c, c->d_queue, 64))) return rc;
     const uint32_t n16 = (uint32_t)pl.ids16.size();
     (void)n16;
-    HIP_TRY(c, hipMemsetAsync(c->d_queue.p, 0, 8, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_queue.p, 0, 32, c->stream));  // queues [0..3], resident counts [4..5]
   }
 #ifdef FLATE_LZ_STAMPS
   if ((rc = ensure(c, c->d_debug, (size_t)pl.n_chunks * 64 + 64))) return rc;
@@ -266,6 +272,17 @@ int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, cons
         G.gtables = c->d_gtables.p;
         G.queue = (uint32_t *)c->d_queue.p + queue_slot;
         G.queue_end = count;
+        c->last_count[queue_slot] = count;
+        LzParams R = G;  // the LDS-table launch counts what it takes
+        R.taken = (uint32_t *)c->d_queue.p + 4 + queue_slot;
+        if (c->profile_split > 0 && c->profile_split < count) {
+          // measurement aid: a fixed split instead of the shared queue, so that a profiler that
+          // serialises the two kernels still sees each of them do its share of the work
+          R.queue_end = c->profile_split;
+          G.queue = (uint32_t *)c->d_queue.p + 2 + queue_slot;
+          G.stream_ids = P.stream_ids + c->profile_split;
+          G.queue_end = count - c->profile_split;
+        }
         (void)hipEventRecord(c->ev_fork, c->stream);
         (void)hipStreamWaitEvent(c->guest_stream, c->ev_fork, 0);
         uint32_t resident = c->resident_blocks < count ? c->resident_blocks : count;
@@ -274,12 +291,12 @@ int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, cons
           hipLaunchKernelGGL(lz77_guest_kernel<true>, dim3((uint32_t)c->guest_blocks), dim3(64), 0,
                              c->guest_stream, G);
           (void)hipEventRecord(c->ev_join, c->guest_stream);
-          hipLaunchKernelGGL(lz77_wave_kernel<true>, dim3(resident), dim3(64), 0, c->stream, G);
+          hipLaunchKernelGGL(lz77_wave_kernel<true>, dim3(resident), dim3(64), 0, c->stream, R);
         } else {
           hipLaunchKernelGGL(lz77_guest_kernel<false>, dim3((uint32_t)c->guest_blocks), dim3(64), 0,
                              c->guest_stream, G);
           (void)hipEventRecord(c->ev_join, c->guest_stream);
-          hipLaunchKernelGGL(lz77_wave_kernel<false>, dim3(resident), dim3(64), 0, c->stream, G);
+          hipLaunchKernelGGL(lz77_wave_kernel<false>, dim3(resident), dim3(64), 0, c->stream, R);
         }
         (void)hipStreamWaitEvent(c->stream, c->ev_join, 0);
       };
@@ -419,6 +436,8 @@ int flate_hip_set_option(flate_hip_ctx *c, const char *name, int64_t value) {
     c->inflate_simt_min = (uint32_t)value;
   } else if (k == "resident_blocks" && value > 0 && value <= 65536) {
     c->resident_blocks = (uint32_t)value;
+  } else if (k == "profile_split_streams" && value >= 0 && value <= 0x7fffffff) {
+    c->profile_split = (uint32_t)value;
   } else if (k == "overlap_sub_batches" && value >= 0 && value <= 64) {
     c->overlap_sub = (int)value;
   } else if (k == "overlap_resident_blocks" && value > 0 && value <= 65536) {
@@ -427,6 +446,17 @@ int flate_hip_set_option(flate_hip_ctx *c, const char *name, int64_t value) {
   } else {
     return FLATE_HIP_E_INVALID;
   }
+  return FLATE_HIP_OK;
+}
+
+int flate_hip_last_resident_share(flate_hip_ctx *c, uint32_t *resident_streams, uint32_t *queued_streams) {
+  if (!c || !resident_streams || !queued_streams) return FLATE_HIP_E_INVALID;
+  *resident_streams = *queued_streams = 0;
+  if (!c->d_queue.p) return FLATE_HIP_OK;
+  uint32_t q[8] = {0};
+  HIP_TRY(c, hipMemcpy(q, c->d_queue.p, 32, hipMemcpyDeviceToHost));
+  *resident_streams = q[4] + q[5];
+  *queued_streams = c->last_count[0] + c->last_count[1];
   return FLATE_HIP_OK;
 }
 

@@ -29,6 +29,8 @@ struct LzParams {
   // sub-batch of the queue (null = off); incremented after the stream's records are visible
   uint32_t *done;
   uint32_t done_shift;
+  // measurement aid: the launch counts the streams it took from the queue here (null = off)
+  uint32_t *taken;
 };
 
 // Entropy stage.  Blocks are the units enc_speed writes: every full 65535-byte window plus the

@@ -668,6 +668,7 @@ __global__ __launch_bounds__(64) void lz77_wave_kernel(LzParams P) {
     lz77_stream<MULTI>(P, P.stream_ids ? P.stream_ids[q] : q, table, lane);
     __syncthreads();
     stream_done(P, q, lane);
+    if (P.taken && lane == 0) __hip_atomic_fetch_add(P.taken, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

@@ -113,6 +113,12 @@ class FlateEngine:
     def set_profiling(self, on=True):
         self._check(self._L.flate_hip_set_profiling(self._ctx, 1 if on else 0))
 
+    def last_resident_share(self):
+        """(streams the LDS-table blocks took, streams queued) of the last persistent match-finder launch."""
+        a, b = C.c_uint32(0), C.c_uint32(0)
+        self._check(self._L.flate_hip_last_resident_share(self._ctx, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def last_timing(self):
         ms = (C.c_float * len(STAGES))()
         self._check(self._L.flate_hip_last_timing(self._ctx, ms, len(STAGES)))
