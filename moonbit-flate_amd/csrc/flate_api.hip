@@ -354,9 +354,7 @@ int flate_hip_init(int device, flate_hip_ctx **out) {
     return FLATE_HIP_E_NO_DEVICE;
   }
   c->stream = c->own_stream;
-  int prio_lo = 0, prio_hi = 0;
-  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-  if (hipStreamCreateWithPriority(&c->ent_stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+  if (hipStreamCreateWithFlags(&c->ent_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_ent, hipEventDisableTiming) != hipSuccess ||
       hipStreamCreateWithFlags(&c->guest_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -569,7 +567,6 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
   H.n_streams = n;
   H.compat_go = (flags & FLATE_HIP_COMPAT_GO) ? 1u : 0u;
   H.sid0 = 0;
-  H.prio = overlap ? 1u : 0u;
   CompactParams C;
   C.out_len = (const uint64_t *)c->d_out_len.p;
   C.out_off = (uint64_t *)c->d_out_off.p;

@@ -59,7 +59,6 @@ struct HuffParams {
   uint32_t n_streams;
   uint32_t compat_go;
   uint32_t sid0;  // first stream of this launch (sub-batched launches; block b handles sid0 + b)
-  uint32_t prio;  // 1: raise the wave priority (the launch runs beside the match finder)
 };
 
 struct CompactParams {

@@ -637,7 +637,6 @@ __global__ __launch_bounds__(64) void huff_hist_kernel(HuffParams P) {
   __shared__ SharedHist sh;
   const int lane = threadIdx.x;
   const uint32_t sid = blockIdx.x + P.sid0;
-  if (P.sid0 != 0xffffffffu && P.prio) __builtin_amdgcn_s_setprio(3);  // beside the match finder: win the issue slots
   if (sid >= P.n_streams) return;
   const BlockGeom g = block_geom(P, sid);
   for (uint32_t b = 0; b < g.nblocks; ++b) {
@@ -704,7 +703,6 @@ __global__ __launch_bounds__(64) void huff_code_kernel(HuffParams P) {
   __shared__ Shared sh;
   const int lane = threadIdx.x;
   const uint32_t sid = blockIdx.x + P.sid0;
-  if (P.sid0 != 0xffffffffu && P.prio) __builtin_amdgcn_s_setprio(3);  // beside the match finder: win the issue slots
   if (sid >= P.n_streams) return;
   const BlockGeom g = block_geom(P, sid);
   uint64_t bitpos = 0;
@@ -808,7 +806,6 @@ __global__ __launch_bounds__(64) void huff_pack_kernel(HuffParams P) {
   __shared__ SharedPack sh;
   const int lane = threadIdx.x;
   const uint32_t sid = blockIdx.x + P.sid0;
-  if (P.sid0 != 0xffffffffu && P.prio) __builtin_amdgcn_s_setprio(3);  // beside the match finder: win the issue slots
   if (sid >= P.n_streams || *P.status != 0) return;
   const BlockGeom g = block_geom(P, sid);
 
