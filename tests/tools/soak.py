@@ -26,6 +26,7 @@ while time.time() - t0 < budget:
     guests = bool(rng.integers(2))
     eng.set_option("guest_min_streams", 1 if guests else 1 << 30)
     eng.set_option("guest_blocks", int(rng.choice([8, 64, 256])) if guests else 0)
+    eng.set_option("overlap_sub_batches", int(rng.choice([0, 0, 2, 8])))  # (only takes effect on uniform batches)
     cm = O.COMPAT_GO if go else O.COMPAT_MOONBIT
     tag = "seed=%d go=%s guests=%s n=%d" % (seed, go, guests, n)
     out, ooff = eng.deflate_batch(data, off, compat_go=go)
@@ -47,6 +48,21 @@ while time.time() - t0 < budget:
         assert bytes(back[:int(off[-1])]) == data[:int(off[-1])].tobytes(), "inflate bytes (%s)" % tag
     back, _, olen, status, _ = eng.inflate_spliced(np.concatenate([one[:nb], np.zeros(8, np.uint8)]), nb, bit_off, szs)
     assert (status == 0).all() and bytes(back[:int(off[-1])]) == data[:int(off[-1])].tobytes(), "inflate_spliced (%s)" % tag
+    if rounds % 7 == 3:  # a uniform batch: the overlapped entropy stage is eligible
+        eng.set_option("guest_min_streams", 1)
+        eng.set_option("guest_blocks", 64)
+        eng.set_option("overlap_sub_batches", int(rng.choice([1, 4, 8, 16])))
+        un = int(rng.integers(64, 400))
+        ulen = int(rng.choice([128, 5000, 65535, 65536, 70000, 140000]))
+        ud = flate.synth("text", un, ulen, first_stream=int(rng.integers(1 << 20)))
+        uo = flate.uniform_offsets(un, ulen)
+        out, ooff = eng.deflate_batch(ud, uo, compat_go=go)
+        ref, roff, rlen = O.deflate_batch(ud, uo, compat=cm, nthreads=8)
+        for i in range(un):
+            assert bytes(out[int(ooff[i]):int(ooff[i + 1])]) == bytes(ref[int(roff[i]):int(roff[i]) + int(rlen[i])]), \
+                "overlapped deflate stream %d differs (%s)" % (i, tag)
+        streams += un
+        nbytes += un * ulen
     rounds += 1
     streams += n
     nbytes += int(off[-1])
