@@ -64,6 +64,9 @@ int flate_hip_set_stream(flate_hip_ctx *ctx, void *hip_stream);
  *                        (default 5 per CU; 0 = off)
  *   "resident_blocks"    persistent LDS-table wavefronts (default 5 per CU)
  *   "guest_min_streams"  batches smaller than this use one block per stream (default 4096)
+ *   "window_units"       1 (default): multi-window streams of a persistent launch are scheduled one
+ *                        65535-byte window at a time (a stream's table rests in global memory
+ *                        between its windows); 0: one block keeps a stream from start to end
  *   "overlap_sub_batches"  > 0: the entropy kernels of every sub-batch (queue order) run on a
  *                        second HIP stream as soon as the match finder has counted its streams
  *                        done (default 0: measured slower on MI355X)

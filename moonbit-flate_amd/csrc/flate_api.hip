@@ -68,6 +68,9 @@ struct flate_hip_ctx {
   hipEvent_t ev_ent = nullptr;
   std::vector<hipEvent_t> ent_ev;    // profiling: start/end of every sub-batch's entropy kernels
   DevBuf d_done;                     // overlap_sub counters + the running output size (u64)
+  // window-granular scheduling of multi-window streams (lz77_kernels.hip, uq_*): on by default
+  int window_units = 1;
+  DevBuf d_uq_ready, d_uq_tables, d_uq_sweep;
   bool overlapped = false;           // what the last encode call did
   // measurement aids (flate_hip_last_resident_share, option "profile_split_streams")
   uint32_t profile_split = 0;        // > 0: LDS-table blocks take exactly the first K queue entries,
@@ -224,7 +227,30 @@ int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, cons
   P.queue_end = 0;
   P.done = overlap_sub ? (uint32_t *)c->d_done.p : nullptr;
   P.taken = nullptr;
+  P.uq_ready = nullptr;
+  P.uq_ctr = nullptr;
+  P.uq_units = 0;
+  P.uq_tables = nullptr;
+  P.uq_sweep = nullptr;
+  P.status = (int *)c->d_status.p;
   c->last_count[0] = c->last_count[1] = 0;
+  // multi-window streams of a persistent launch run one window at a time (see uq_run): the
+  // streams' tables rest in global memory between windows (32 KiB each; beyond 4 GiB of them the
+  // launch falls back to one block per stream at a time; the ready word limits it to 2^17 - 2 streams)
+  uint32_t uq_units = 0;
+  const size_t n32 = pl.ids32.size();
+  const bool use_uq = c->window_units && c->guest_blocks > 0 && n32 >= c->guest_min &&
+                      n32 < (1u << 17) - 1u && !(flags & FLATE_HIP_LZ_SERIAL);
+  if (use_uq) {
+    uint64_t units = 0;
+    for (uint32_t sid : pl.ids32) units += pl.chunk_base[sid + 1] - pl.chunk_base[sid];
+    if (units < 0xffffffffull) uq_units = (uint32_t)units;
+  }
+  if (uq_units) {
+    if ((rc = ensure(c, c->d_uq_ready, (size_t)uq_units * 4 + 64))) return rc;
+    if ((rc = ensure(c, c->d_uq_tables, n32 * (size_t)kTableSize * 2 + 64))) return rc;
+    if ((rc = ensure(c, c->d_uq_sweep, n32 * 4 + 64))) return rc;
+  }
   P.done_shift = 0;
   while (overlap_sub && (1u << P.done_shift) < overlap_sub) ++P.done_shift;  // (a power of two)
   if (c->guest_blocks > 0) {
@@ -273,9 +299,19 @@ int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, cons
         G.queue = (uint32_t *)c->d_queue.p + queue_slot;
         G.queue_end = count;
         c->last_count[queue_slot] = count;
+        if (multi && uq_units) {
+          G.uq_ready = (uint32_t *)c->d_uq_ready.p;
+          G.uq_ctr = (uint32_t *)c->d_queue.p + 6;  // {head, tail}
+          G.uq_units = uq_units;
+          G.uq_tables = (uint16_t *)c->d_uq_tables.p;
+          G.uq_sweep = (uint32_t *)c->d_uq_sweep.p;
+          c->last_count[queue_slot] = uq_units;
+          hipLaunchKernelGGL(uq_init_kernel, dim3((uq_units + 255) / 256), dim3(256), 0, c->stream,
+                             G.uq_ready, G.uq_ctr, count, uq_units);
+        }
         LzParams R = G;  // the LDS-table launch counts what it takes
         R.taken = (uint32_t *)c->d_queue.p + 4 + queue_slot;
-        if (c->profile_split > 0 && c->profile_split < count) {
+        if (c->profile_split > 0 && c->profile_split < count && !G.uq_ready) {
           // measurement aid: a fixed split instead of the shared queue, so that a profiler that
           // serialises the two kernels still sees each of them do its share of the work
           R.queue_end = c->profile_split;
@@ -409,6 +445,9 @@ void flate_hip_destroy(flate_hip_ctx *c) {
   for (auto &e : c->ent_ev)
     if (e) (void)hipEventDestroy(e);
   release(c->d_done);
+  release(c->d_uq_ready);
+  release(c->d_uq_tables);
+  release(c->d_uq_sweep);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -436,6 +475,8 @@ int flate_hip_set_option(flate_hip_ctx *c, const char *name, int64_t value) {
     c->resident_blocks = (uint32_t)value;
   } else if (k == "profile_split_streams" && value >= 0 && value <= 0x7fffffff) {
     c->profile_split = (uint32_t)value;
+  } else if (k == "window_units" && (value == 0 || value == 1)) {
+    c->window_units = (int)value;
   } else if (k == "overlap_sub_batches" && value >= 0 && value <= 64) {
     c->overlap_sub = (int)value;
   } else if (k == "overlap_resident_blocks" && value > 0 && value <= 65536) {
@@ -630,6 +671,10 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
   HIP_TRY(c, hipMemcpyAsync(&c->h_status_word, c->d_status.p, 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (c->h_status_word) {
+    if (c->h_status_word == FLATE_HIP_E_INTERNAL) {
+      c->hip_err = "a match-finder block waited for a window that was never handed over";
+      return FLATE_HIP_E_INTERNAL;
+    }
     if (c->h_status_word <= -0x100000) {  // encoder self-check (huff_pack_kernel): -(0x100000 + stream)
       c->hip_err = "packed bits differ from the computed block size in stream " +
                    std::to_string((uint32_t)(-c->h_status_word) - 0x100000u) + " (mod 2^20)";
@@ -721,10 +766,13 @@ int flate_hip_lz77_matches(flate_hip_ctx *c, const uint8_t *in, const uint64_t *
     HIP_TRY(c, hipMemcpyAsync(c->d_in.p, in, in_off[n], hipMemcpyHostToDevice, c->stream));
     d_in = (const uint8_t *)c->d_in.p;
   }
+  HIP_TRY(c, hipMemsetAsync(c->d_status.p, 0, 4, c->stream));
   if ((rc = run_lz77(c, d_in, in_off, pl, flags))) return rc;
   HIP_TRY(c, hipMemcpyAsync(chunk_nmatch, c->d_nmatch.p, (size_t)pl.n_chunks * 4,
                             hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(&c->h_status_word, c->d_status.p, 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->h_status_word) return c->h_status_word;
   for (uint32_t k = 0; k <= pl.n_chunks; ++k) chunk_rec_off[k] = (uint64_t)k * kMatchCapPerChunk;
   const hipMemcpyKind kind = dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
   HIP_TRY(c, hipMemcpyAsync(recs, c->d_matches.p, (size_t)pl.n_chunks * kMatchCapPerChunk * 8, kind,

@@ -31,6 +31,16 @@ struct LzParams {
   uint32_t done_shift;
   // measurement aid: the launch counts the streams it took from the queue here (null = off)
   uint32_t *taken;
+  // Window-granular scheduling of multi-window streams (persistent MULTI launches): the unit of
+  // work is one LZ77 window of one stream.  uq_ready[k] = (queue entry + 1) << 15 | window of the
+  // k-th unit to run (0 = not pushed yet); uq_ctr = {head, tail}; the table of a stream between
+  // two of its windows lives in uq_tables (32 KiB per queue entry), its sweep clock in uq_sweep.
+  uint32_t *uq_ready;
+  uint32_t *uq_ctr;
+  uint32_t uq_units;
+  uint16_t *uq_tables;
+  uint32_t *uq_sweep;
+  int *status;
 };
 
 // Entropy stage.  Blocks are the units enc_speed writes: every full 65535-byte window plus the
@@ -98,6 +108,7 @@ __global__ void lz77_guest_kernel(LzParams P);
 __global__ void huff_hist_kernel(HuffParams P);
 __global__ void huff_code_kernel(HuffParams P);
 __global__ void huff_pack_kernel(HuffParams P);
+__global__ void uq_init_kernel(uint32_t *ready, uint32_t *ctr, uint32_t n_streams, uint32_t n_units);
 __global__ void scan_sizes_kernel(CompactParams P);
 // spins (bounded) until *counter >= target: gates a sub-batch of the entropy stage on the match
 // finder that is still running on another stream

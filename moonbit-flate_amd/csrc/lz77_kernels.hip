@@ -156,10 +156,15 @@ __global__ __launch_bounds__(64) void lz77_serial_kernel(LzParams P) {
 
 // GUEST: the table is a slice of HBM scratch living in L2 (lz77_guest_kernel).  Same algorithm;
 // only the detection of lanes that share a slot avoids the table there (see the dense batch).
+// c_begin .. c_end: the LZ77 windows of the stream to run (default: all of them, starting from an
+// empty table).  A caller that runs one window at a time keeps the table itself and passes the
+// sweep clock through *sweep_io.
 template <bool MULTI, bool GUEST = false>
-FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table, const int lane) {
+FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table, const int lane,
+                         const uint32_t c_begin = 0, const uint32_t c_end = 0xffffffffu,
+                         uint32_t *sweep_io = nullptr) {
   using E = uint16_t;
-  {
+  if (c_begin == 0) {
     uint4 *t4 = reinterpret_cast<uint4 *>(table);
     const uint32_t fill = MULTI ? (((0u - kMarkerBack + 1u) & 0xffffu) * 0x10001u) : 0u;
     const uint4 z = make_uint4(fill, fill, fill, fill);
@@ -168,7 +173,8 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
   __syncthreads();
   volatile E *vtable = table;
   constexpr uint32_t kEMask = 0xffffu;
-  uint32_t next_sweep = kSweepEvery;  // MULTI: absolute position at which the next sweep is due
+  // MULTI: absolute position at which the next sweep is due
+  uint32_t next_sweep = (sweep_io && c_begin != 0) ? *sweep_io : kSweepEvery;
   // Sweep: slots whose position is more than 32768 behind R can never be candidates again.
   auto sweep = [&](uint32_t R) {
     uint32_t *t32 = reinterpret_cast<uint32_t *>(table);
@@ -188,7 +194,8 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
   const uint16_t *scan_tab = P.scan_off;
   uint32_t pf_val = 0, pf_sink = 0;
 
-  for (uint32_t c = 0; c < g.nchunks; ++c) {
+  const uint32_t c_stop = c_end < g.nchunks ? c_end : g.nchunks;
+  for (uint32_t c = c_begin; c < c_stop; ++c) {
     const uint32_t W = c * (uint32_t)kMaxStoreBlockSize;
     const uint64_t rem_len = g.len - W;
     const int n = rem_len < (uint64_t)kMaxStoreBlockSize ? (int)rem_len : kMaxStoreBlockSize;
@@ -634,6 +641,7 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
 #endif
     }
   }
+  if (sweep_io) *sweep_io = next_sweep;
 }
 
 // Overlap with the entropy stage (flate_api.hip): queue entry q is finished -- make its match
@@ -646,11 +654,131 @@ FLATE_D void stream_done(const LzParams &P, uint32_t q, int lane) {
     __hip_atomic_fetch_add(P.done + (q >> P.done_shift), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---------------------------------------------------------------------------------
+// Window-granular scheduling of multi-window streams.  A stream's windows are sequential (the
+// table carries over, deflate-fast.mbt:156,193), so with one wavefront per STREAM a batch of
+// n streams on S table slots takes ceil(n / S) whole-stream rounds -- 4096 streams of four windows
+// on 2560 slots: two rounds, the second 60 % full.  Here the unit of work is one WINDOW: every
+// block pops the next ready unit {stream, window} from one FIFO, runs that window, and pushes the
+// stream's next window to the back.  All first windows are ready at the start, so the order is
+// breadth-first and every slot stays busy until the last window time.  Between two of its
+// windows a stream's table rests in global memory (uq_tables, 32 KiB per stream): LDS-table blocks
+// load it into LDS and store it back, guest blocks work on it in place.
+// ---------------------------------------------------------------------------------
+struct UqUnit {
+  uint32_t q;  // queue entry (index into stream_ids)
+  uint32_t c;  // LZ77 window of that stream
+  bool ok;
+};
+
+// Pop the next unit: a ticket from the head counter, then wait until the unit with that ticket
+// has been pushed (its producer is a block that is running a window right now, so the wait is
+// bounded by one window time; a bounded spin turns anything else into an error, not a hang).
+FLATE_D UqUnit uq_pop(const LzParams &P, const uint32_t push_word, int lane) {
+  // One lane-0 block per loop iteration: publish the window this block has just finished with
+  // (push_word != 0; its payload was stored write-through and drained by every storing lane, the
+  // window's match records are read only by later kernels), then take a ticket.  (Two separate
+  // lane-0 blocks, one at the end and one at the start of the loop body, made the compiler peel
+  // lane 0 off the unit loop: after the first unit the guest blocks ran without it.)
+  uint32_t t = 0;
+  if (lane == 0) {
+    if (push_word != 0) {
+      const uint32_t k = __hip_atomic_fetch_add(P.uq_ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(P.uq_ready + k, push_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    t = __hip_atomic_fetch_add(P.uq_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+  const uint32_t units = P.uq_units;
+  uint32_t v = 0;
+  if (t < units) {
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+      uint32_t x = 0;
+      if (lane == 0) x = __hip_atomic_load(P.uq_ready + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v = (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
+      if (v != 0) break;
+      if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) break;  // ~4 s of the 100 MHz counter
+      __builtin_amdgcn_s_sleep(16);
+    }
+    if (v == 0 && lane == 0) atomicExch(P.status, -8);  // FLATE_HIP_E_INTERNAL: gave up
+    // acquire (one lane: the invalidate is per CU) before anyone reads the producer's payload
+    if (lane == 0) (void)__hip_atomic_load(P.uq_ready + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  UqUnit u;
+  v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+  u.ok = v != 0;
+  u.q = (v >> 15) - 1u;  // ready word = (queue entry + 1) << 15 | window (entry < 2^17 - 1, window < 2^15)
+  u.c = v & 0x7fffu;
+  return u;
+}
+
+__global__ void uq_init_kernel(uint32_t *ready, uint32_t *ctr, uint32_t n_streams, uint32_t n_units) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_units) ready[i] = i < n_streams ? ((i + 1u) << 15) : 0u;  // {entry i, window 0}
+  if (i == 0) {
+    ctr[0] = 0;
+    ctr[1] = n_streams;
+  }
+}
+
+// One unit.  The working table is the block's own (LDS, or the guest block's slice of HBM); the
+// stream's table travels through uq_tables.  The hand-off follows the write-through form of the
+// inter-workgroup rules for gfx950 (private, mutually incoherent L2 per XCD): every payload word
+// (table, sweep clock) is stored and loaded with agent-scope relaxed atomics -- `sc1` accesses that
+// go past L1 and are written through L2 -- every storing lane drains its stores, then one lane
+// publishes the ready word; the consumer polls that word and acquires once (uq_pop).
+template <bool GUEST>
+FLATE_D uint32_t uq_run(const LzParams &P, const UqUnit u, uint16_t *table, int lane) {
+  // (wave-uniform values made scalar explicitly: with a per-lane `nch` the branch around the push
+  // below is divergent for the compiler, which then peels lane 0 off the unit loop)
+  const uint32_t sid = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.stream_ids[u.q]);
+  const uint32_t nch = (uint32_t)__builtin_amdgcn_readfirstlane((int)(P.chunk_base[sid + 1] - P.chunk_base[sid]));
+  uint32_t *home = reinterpret_cast<uint32_t *>(P.uq_tables + (size_t)u.q * kTableSize);
+  uint32_t *work = reinterpret_cast<uint32_t *>(table);
+  uint32_t clock = 0;
+  if (u.c != 0) {
+    clock = (uint32_t)__builtin_amdgcn_readfirstlane(
+        (int)__hip_atomic_load(P.uq_sweep + u.q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    for (int i = lane; i < kTableSize / 2; i += 64)
+      work[i] = __hip_atomic_load(home + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  lz77_stream<true, GUEST>(P, sid, table, lane, u.c, u.c + 1, &clock);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (u.c + 1 < nch) {
+    for (int i = lane; i < kTableSize / 2; i += 64)
+      __hip_atomic_store(home + i, work[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) __hip_atomic_store(P.uq_sweep + u.q, clock, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // every storing lane drains
+    __syncthreads();
+    return ((u.q + 1u) << 15) | (u.c + 1u);  // the ready word of the stream's next window
+  }
+  stream_done(P, u.q, lane);
+  return 0u;
+}
+
 // Resident kernel: table in LDS (32 KiB per stream => 5 streams per CU).
 template <bool MULTI>
 __global__ __launch_bounds__(64) void lz77_wave_kernel(LzParams P) {
   __shared__ uint16_t table[kTableSize];
   const int lane = threadIdx.x;
+  if (MULTI && P.uq_ready) {  // persistent, one window at a time (see uq_run)
+    uint32_t push_word = 0;
+    uint32_t mine = 0;
+    for (;;) {
+      const UqUnit u = uq_pop(P, push_word, lane);
+      if (__builtin_amdgcn_readfirstlane((int)u.ok) == 0) break;
+      push_word = (uint32_t)__builtin_amdgcn_readfirstlane((int)uq_run<false>(P, u, table, lane));
+      ++mine;
+    }
+    if (P.taken && lane == 0) __hip_atomic_fetch_add(P.taken, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   // Either one block per stream (P.queue == null) or persistent: resident and guest blocks
   // share one queue (dynamic balance).  One call site keeps a single copy of the parser.
   for (bool first = true;; first = false) {
@@ -680,6 +808,15 @@ template <bool MULTI>
 __global__ __launch_bounds__(64) void lz77_guest_kernel(LzParams P) {
   uint16_t *table = reinterpret_cast<uint16_t *>(P.gtables) + (size_t)blockIdx.x * kTableSize;
   const int lane = threadIdx.x;
+  if (MULTI && P.uq_ready) {  // persistent, one window at a time, table in place (see uq_run)
+    uint32_t push_word = 0;
+    for (;;) {
+      const UqUnit u = uq_pop(P, push_word, lane);
+      if (__builtin_amdgcn_readfirstlane((int)u.ok) == 0) break;
+      push_word = (uint32_t)__builtin_amdgcn_readfirstlane((int)uq_run<true>(P, u, table, lane));
+    }
+    return;
+  }
   for (;;) {
     uint32_t q = 0;
     if (lane == 0) q = atomicAdd(P.queue, 1u);
