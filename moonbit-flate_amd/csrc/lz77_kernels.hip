@@ -645,12 +645,13 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
 }
 
 // Overlap with the entropy stage (flate_api.hip): queue entry q is finished -- make its match
-// records and counts visible device-wide, then count it in its sub-batch.
-FLATE_D void stream_done(const LzParams &P, uint32_t q, int lane) {
-  if (!P.done) return;
-  // (the release covers the whole wavefront's stores: the wait the compiler emits in front of the
-  // L2 write-back is the wave's vmcnt, and a wave barrier precedes this call)
-  if (lane == 0)
+// records and counts visible device-wide, then count it in its sub-batch.  Called by ONE lane, from
+// the single lane-0 block of the persistent loops (a second lane-0 block at the end of the loop
+// body next to the one at its start made the compiler peel lane 0 off the loop: see uq_pop); the
+// release covers the whole wavefront's stores: the wait the compiler emits in front of the L2
+// write-back is the wave's vmcnt, and a wave barrier precedes the call.
+FLATE_D void stream_done_lane0(const LzParams &P, uint32_t q) {
+  if (P.done)
     __hip_atomic_fetch_add(P.done + (q >> P.done_shift), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -676,13 +677,15 @@ struct UqUnit {
 // bounded by one window time; a bounded spin turns anything else into an error, not a hang).
 FLATE_D UqUnit uq_pop(const LzParams &P, const uint32_t push_word, int lane) {
   // One lane-0 block per loop iteration: publish the window this block has just finished with
-  // (push_word != 0; its payload was stored write-through and drained by every storing lane, the
+  // (push_word: 0 = nothing, bit 31 = that stream is complete, else the next window's ready word; its payload was stored write-through and drained by every storing lane, the
   // window's match records are read only by later kernels), then take a ticket.  (Two separate
   // lane-0 blocks, one at the end and one at the start of the loop body, made the compiler peel
   // lane 0 off the unit loop: after the first unit the guest blocks ran without it.)
   uint32_t t = 0;
   if (lane == 0) {
-    if (push_word != 0) {
+    if (push_word & 0x80000000u) {  // the previous unit was its stream's last window
+      stream_done_lane0(P, push_word & 0x7fffffffu);
+    } else if (push_word != 0) {
       const uint32_t k = __hip_atomic_fetch_add(P.uq_ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(P.uq_ready + k, push_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -758,8 +761,7 @@ FLATE_D uint32_t uq_run(const LzParams &P, const UqUnit u, uint16_t *table, int 
     __syncthreads();
     return ((u.q + 1u) << 15) | (u.c + 1u);  // the ready word of the stream's next window
   }
-  stream_done(P, u.q, lane);
-  return 0u;
+  return 0x80000000u | u.q;  // the stream is finished (entry < 2^17: the flag bit is free)
 }
 
 // Resident kernel: table in LDS (32 KiB per stream => 5 streams per CU).
@@ -781,11 +783,15 @@ __global__ __launch_bounds__(64) void lz77_wave_kernel(LzParams P) {
   }
   // Either one block per stream (P.queue == null) or persistent: resident and guest blocks
   // share one queue (dynamic balance).  One call site keeps a single copy of the parser.
+  uint32_t mine = 0, prev = 0xffffffffu;  // streams taken; the entry finished in the previous round
   for (bool first = true;; first = false) {
     uint32_t q;
     if (P.queue) {
       q = 0;
-      if (lane == 0) q = atomicAdd(P.queue, 1u);
+      if (lane == 0) {  // the ONE lane-0 block of the loop (see stream_done_lane0)
+        if (prev != 0xffffffffu) stream_done_lane0(P, prev);
+        q = atomicAdd(P.queue, 1u);
+      }
       q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
       if (q >= P.queue_end) break;
     } else {
@@ -795,9 +801,10 @@ __global__ __launch_bounds__(64) void lz77_wave_kernel(LzParams P) {
     __syncthreads();
     lz77_stream<MULTI>(P, P.stream_ids ? P.stream_ids[q] : q, table, lane);
     __syncthreads();
-    stream_done(P, q, lane);
-    if (P.taken && lane == 0) __hip_atomic_fetch_add(P.taken, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    prev = q;
+    ++mine;
   }
+  if (P.taken && lane == 0) __hip_atomic_fetch_add(P.taken, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Guest kernel: the LDS of a CU holds only five 32 KiB tables, but its SIMDs are mostly idle
@@ -817,15 +824,19 @@ __global__ __launch_bounds__(64) void lz77_guest_kernel(LzParams P) {
     }
     return;
   }
+  uint32_t prev = 0xffffffffu;
   for (;;) {
     uint32_t q = 0;
-    if (lane == 0) q = atomicAdd(P.queue, 1u);
+    if (lane == 0) {  // the ONE lane-0 block of the loop (see stream_done_lane0)
+      if (prev != 0xffffffffu) stream_done_lane0(P, prev);
+      q = atomicAdd(P.queue, 1u);
+    }
     q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
     if (q >= P.queue_end) break;
     __syncthreads();
     lz77_stream<MULTI, true>(P, P.stream_ids[q], table, lane);
     __syncthreads();
-    stream_done(P, q, lane);
+    prev = q;
   }
 }
 
