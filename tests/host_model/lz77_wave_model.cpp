@@ -13,7 +13,7 @@ namespace {
 constexpr int kTableSize = 16384;
 constexpr int kWin = 65535;
 constexpr int kSmallLzMin = 128;
-constexpr int kDenseKeep = 58;  // continue in the same dense batch while the next s-1 lane <= this
+constexpr int kDenseKeep = 61;  // continue in the same dense batch while the next s-1 lane <= this
 
 inline uint32_t ld32(const uint8_t *p) {
   uint32_t v;
