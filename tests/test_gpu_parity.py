@@ -250,5 +250,19 @@ def test_overlapped_entropy_stage_is_bit_exact(oracle):
                 a = out[int(out_off[i]):int(out_off[i + 1])]
                 b = want[int(w_off[i]):int(w_off[i]) + int(w_len[i])]
                 assert a.size == b.size and np.array_equal(a, b), (sub, i)
+        # multi-window streams: the match finder then hands windows between blocks (window units)
+        # while the entropy stage of finished sub-batches already runs
+        n2, blen2 = 192, 150000
+        data2 = flate.synth("text", n2, blen2, first_stream=5000)
+        off2 = flate.uniform_offsets(n2, blen2)
+        want2, w_off2, w_len2 = oracle.deflate_batch(data2, off2, nthreads=8)
+        for sub, units in ((8, 1), (8, 0), (0, 1)):
+            e.set_option("overlap_sub_batches", sub)
+            e.set_option("window_units", units)
+            out, out_off = e.deflate_batch(data2, off2)
+            for i in range(n2):
+                a = out[int(out_off[i]):int(out_off[i + 1])]
+                b = want2[int(w_off2[i]):int(w_off2[i]) + int(w_len2[i])]
+                assert a.size == b.size and np.array_equal(a, b), ("multi", sub, units, i)
     finally:
         e.close()
