@@ -517,6 +517,53 @@ def extra_legs(args, env):
     8 GiB of output, output == input on every byte).  Same engine, same measurement rules."""
     torch, np, flate, eng, dev = (env[k] for k in ("torch", "np", "flate", "eng", "dev"))
     extra = {}
+    # ---- the headline shape on the other synthetic inputs of BASELINE.md (S-ramp, S-zero, S-rand) and
+    # the same call with HOST pointers (one H2D of the input + one D2H of the output inside the call:
+    # the PCIe-inclusive rate; never the headline value)
+    n, blen = 16384, 65536
+    in_off = flate.uniform_offsets(n, blen)
+    out = torch.empty(n * blen + (n * blen >> 3) + 4096, dtype=torch.uint8, device=dev)
+    others = {}
+    for kind in ("ramp", "zero", "rand", "text"):
+        host = flate.synth(kind, n, blen)
+        d_in = torch.from_numpy(host).to(dev)
+        eng.deflate_batch(d_in, in_off, out=out)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            t1 = time.perf_counter()
+            _, out_off = eng.deflate_batch(d_in, in_off, out=out)
+            ts.append(time.perf_counter() - t1)
+        clen = int(out_off[-1])
+        checked = 0
+        if args.verify and not args.no_cpu_baseline:
+            from oracle import pyoracle
+            g_cpu = out[:clen].cpu().numpy()
+            for i in range(0, n, 256):
+                if bytes(g_cpu[int(out_off[i]):int(out_off[i + 1])]) != pyoracle.deflate(host[i * blen:(i + 1) * blen]):
+                    raise SystemExit("PARITY FAILURE (S-%s) at stream %d" % (kind, i))
+                checked += 1
+        if kind != "text":
+            others["S-" + kind] = {"value": round(n * blen / min(ts) / 2**30, 2), "unit": "GiB/s", "ratio": round(n * blen / clen, 3),
+                                   "step_ms": summarize(ts), "parity_checked_streams": checked}
+        else:  # host pointers
+            h_out = np.empty(out.numel(), dtype=np.uint8)
+            eng.deflate_batch(host, in_off, out=h_out)
+            ts = []
+            for _ in range(2):
+                t1 = time.perf_counter()
+                _, h_off = eng.deflate_batch(host, in_off, out=h_out)
+                ts.append(time.perf_counter() - t1)
+            if int(h_off[-1]) != clen:
+                raise SystemExit("host-pointer call produced a different size")
+            extra["end_to_end_host_pointers"] = {
+                "value": round(n * blen / min(ts) / 2**30, 2), "unit": "GiB/s", "step_ms": summarize(ts),
+                "note": "same workload, input and output in pageable host memory: the call copies 1 GiB in and "
+                        "%.2f GiB out over PCIe (not the headline value)" % (clen / 2**30)}
+        del host, d_in
+    extra["other_inputs_16384x65536"] = others
+    del out
+    torch.cuda.empty_cache()
     # ---- configs[2]
     n, blen = 4096, 262144
     host = flate.synth("text", n, blen)
