@@ -256,9 +256,9 @@ int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, cons
   if (c->guest_blocks > 0) {
     if ((rc = ensure(c, c->d_gtables, (size_t)c->guest_blocks * kTableSize * 2 + 64))) return rc;
     if ((rc = ensure(c, c->d_queue, 64))) return rc;
-    const uint32_t n16 = (uint32_t)pl.ids16.size();
-    (void)n16;
-    HIP_TRY(c, hipMemsetAsync(c->d_queue.p, 0, 32, c->stream));  // queues [0..3], resident counts [4..5]
+    // words: [0..1] stream queues (single-, multi-window), [2..3] the guests' queues of a fixed
+    // profiling split, [4..5] what the LDS-table launches took, [6..7] window-unit head / tail
+    HIP_TRY(c, hipMemsetAsync(c->d_queue.p, 0, 32, c->stream));
   }
 #ifdef FLATE_LZ_STAMPS
   if ((rc = ensure(c, c->d_debug, (size_t)pl.n_chunks * 64 + 64))) return rc;
