@@ -61,8 +61,8 @@ void flate_hip_destroy(flate_hip_ctx *ctx);
 int flate_hip_set_stream(flate_hip_ctx *ctx, void *hip_stream);
 /* Tuning knobs of the match finder's launch geometry (results never change):
  *   "guest_blocks"       extra persistent wavefronts whose hash table lives in L2 instead of LDS
- *                        (default 5 per CU; 0 = off)
- *   "resident_blocks"    persistent LDS-table wavefronts (default 5 per CU)
+ *                        (default 6.5 per CU; 0 = off)
+ *   "resident_blocks"    persistent LDS-table wavefronts (default 4 per CU)
  *   "guest_min_streams"  batches smaller than this use one block per stream (default 4096)
  *   "window_units"       1 (default): multi-window streams of a persistent launch are scheduled one
  *                        65535-byte window at a time (a stream's table rests in global memory

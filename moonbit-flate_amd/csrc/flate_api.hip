@@ -55,7 +55,7 @@ struct flate_hip_ctx {
   // streams whatever the batch size, the wave-per-stream one ~13 ms per 1024 streams (measured:
   // tools/inflate_crossover.py)
   uint32_t inflate_simt_min = 2049;
-  uint32_t resident_blocks = 1280;  // persistent LDS-table blocks (5 per CU x 256 CUs)
+  uint32_t resident_blocks = 1024;  // persistent LDS-table blocks (4 per CU x 256 CUs)
   // Entropy stage overlapped with the match finder: the batch is cut into overlap_sub sub-batches
   // (queue order); hist/code/scan/pack of a sub-batch run on ent_stream as soon as the match finder
   // -- one launch over the whole batch -- has counted all of its streams done.  0 = off (default:
@@ -398,14 +398,15 @@ int flate_hip_init(int device, flate_hip_ctx **out) {
     flate_hip_destroy(c);
     return FLATE_HIP_E_HIP;
   }
-  {  // 5 resident (LDS-table) + 5 guest (L2-table) match-finder waves per CU (measured best)
+  {  // 4 resident (LDS-table) + 6.5 guest (L2-table, 4 KiB of LDS slot tags each) match-finder
+     // waves per CU: measured best for single- and multi-window streams (profiles/r02/README.md)
     hipDeviceProp_t prop;
     int cus = 256;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
       cus = prop.multiProcessorCount;
     c->num_cus = (uint32_t)cus;
-    c->resident_blocks = 5u * (uint32_t)cus;
-    c->guest_blocks = 5 * cus;
+    c->resident_blocks = 4u * (uint32_t)cus;
+    c->guest_blocks = 13 * cus / 2;
     c->overlap_resident = 4u * (uint32_t)cus;
   }
   if (const char *e = getenv("FLATE_HIP_GUEST_BLOCKS")) c->guest_blocks = atoi(e) < 0 ? 0 : atoi(e);

@@ -159,11 +159,29 @@ __global__ __launch_bounds__(64) void lz77_serial_kernel(LzParams P) {
 // c_begin .. c_end: the LZ77 windows of the stream to run (default: all of them, starting from an
 // empty table).  A caller that runs one window at a time keeps the table itself and passes the
 // sweep clock through *sweep_io.
+//
+// tags (guest blocks of single-window launches, else null): 2 bits per slot in LDS, a function of
+// the four bytes at the position the slot holds (bits 17:16 of the hash product; the slot index is
+// bits 31:18).  A lane whose own tag differs from its slot's tag cannot have a valid candidate --
+// the reference would read the slot and fail `cv == cand.val` (deflate-fast.mbt:196) -- so it
+// skips both the table gather and the candidate gather: the guest tables live in the Infinity
+// Cache (profiles/r02/lz77_traffic.json) and those gathers are what fills the vector L1's miss
+// queue.  Exact: every table write also writes the tag.
+FLATE_D uint32_t tag_of(uint32_t cv) { return ((cv * 0x1e35a7bdu) >> 16) & 3u; }
+FLATE_D uint32_t tag_get(const uint32_t *tags, uint32_t h) { return (tags[h >> 4] >> (2u * (h & 15u))) & 3u; }
+FLATE_D void tag_set(uint32_t *tags, uint32_t h, uint32_t t) {
+  const uint32_t sh = 2u * (h & 15u);
+  atomicAnd(&tags[h >> 4], ~(3u << sh));
+  atomicOr(&tags[h >> 4], t << sh);
+}
+
 template <bool MULTI, bool GUEST = false>
 FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table, const int lane,
                          const uint32_t c_begin = 0, const uint32_t c_end = 0xffffffffu,
-                         uint32_t *sweep_io = nullptr) {
+                         uint32_t *sweep_io = nullptr, uint32_t *tags = nullptr) {
   using E = uint16_t;
+  if (tags && c_begin == 0)
+    for (int i = lane; i < kTableSize / 16; i += 64) tags[i] = 0;
   if (c_begin == 0) {
     uint4 *t4 = reinterpret_cast<uint4 *>(table);
     const uint32_t fill = MULTI ? (((0u - kMarkerBack + 1u) & 0xffffu) * 0x10001u) : 0u;
@@ -231,16 +249,18 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
         const uint32_t A1 = W + (uint32_t)q + 1;
         uint4 own = make_uint4(0, 0, 0, 0);
         uint32_t h = 0, old = 0;
+        bool maybe = false;  // my slot may hold a position with my four bytes
         pf_sink ^= pf_val;  // retire the previous batch's look-ahead load
         if (e1) {
           own = pre_valid ? own_pre : ld128(src + q);
           h = hash4(own.x);
-          old = table[h];
+          maybe = !tags || tag_get(tags, h) == tag_of(own.x);
+          if (maybe) old = table[h];
         }
         pre_valid = false;
         // candidate = absolute position stored in my slot; valid if within 32768 (:195)
         const uint32_t dist = MULTI ? ((A1 - old) & 0xffffu) : (A1 - old);
-        const bool inr = e1 && (MULTI ? dist != 0 : old != 0) && dist <= (uint32_t)kMaxMatchOffset;
+        const bool inr = maybe && (MULTI ? dist != 0 : old != 0) && dist <= (uint32_t)kMaxMatchOffset;
         const uint32_t cand_abs = A1 - 1u - dist;
         uint4 cb = own;
         if (inr) cb = ld128(g.stream + cand_abs);
@@ -497,7 +517,10 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
         if (GUEST) {
           // the table is still untouched: the inserted lanes write, and where several share a
           // slot only the last of them (position order: the latest insert wins)
-          if (e1 && ((INS >> lane) & 1) && (eq & INS & ~lanes_upto(lane)) == 0) table[h] = (E)A1;
+          if (e1 && ((INS >> lane) & 1) && (eq & INS & ~lanes_upto(lane)) == 0) {
+            table[h] = (E)A1;
+            if (tags) tag_set(tags, h, tag_of(own.x));
+          }
         } else {
           if (e1 && (((DUPall | ~INS) >> lane) & 1)) table[h] = (E)old;
           uint64_t dm = DUPall & INS;
@@ -566,7 +589,10 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
             eqs &= bit ? m : ~m;
           }
           C = __ballot(ins && (eqs & ~(1ull << lane)) != 0);
-          if (C == 0 && ins) vtable[h] = (E)A1;
+          if (C == 0 && ins) {
+            vtable[h] = (E)A1;
+            if (tags) tag_set(tags, h, tag_of(cv));
+          }
         } else {
           if (ins) vtable[h] = (E)A1;
           const uint32_t rb = ins ? (uint32_t)vtable[h] : (A1 & kEMask);
@@ -587,6 +613,7 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
             const uint32_t cur =
                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)vtable[he]);
             vtable[he] = (E)pe1;
+            if (tags && lane == e2) tag_set(tags, h, tag_of(cv));
             bool v;
             uint32_t cnd;
             if (cur == rdlane(old, e2)) {
@@ -815,6 +842,11 @@ template <bool MULTI>
 __global__ __launch_bounds__(64) void lz77_guest_kernel(LzParams P) {
   uint16_t *table = reinterpret_cast<uint16_t *>(P.gtables) + (size_t)blockIdx.x * kTableSize;
   const int lane = threadIdx.x;
+  uint32_t *tags = nullptr;
+  if constexpr (!MULTI) {  // multi-window streams gain nothing from it (profiles/r02/README.md)
+    __shared__ uint32_t tag_mem[kTableSize / 16];  // 4 KiB: see tag_of
+    tags = tag_mem;
+  }
   if (MULTI && P.uq_ready) {  // persistent, one window at a time, table in place (see uq_run)
     uint32_t push_word = 0;
     for (;;) {
@@ -834,7 +866,7 @@ __global__ __launch_bounds__(64) void lz77_guest_kernel(LzParams P) {
     q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
     if (q >= P.queue_end) break;
     __syncthreads();
-    lz77_stream<MULTI, true>(P, P.stream_ids[q], table, lane);
+    lz77_stream<MULTI, true>(P, P.stream_ids[q], table, lane, 0, 0xffffffffu, nullptr, tags);
     __syncthreads();
     prev = q;
   }
