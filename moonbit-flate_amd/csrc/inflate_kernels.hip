@@ -563,7 +563,8 @@ constexpr int kOffLens = kOffDistMeta + 16;           // 352 code lengths (32 + 
 constexpr int kLaneWords = kOffLens + 88;             // 296
 
 enum SState { S_BLOCK = 0, S_DYN_LENS, S_SYM, S_DIST, S_STORED, S_DONE };
-constexpr int kSymPerStep = 4;  // literal/length symbols one lane may decode per step
+// literal/length symbols one lane may decode per step (measured on config 5: 2 -4 %, 3 = 4, 6 -9 %)
+constexpr int kSymPerStep = 4;
 
 // The 15 code-length limits of one Huffman code, two per register (see shuff_sym).
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
@@ -821,7 +822,10 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
   Limits lit_lim, dist_lim;       // dist_lim also serves the code-length code
   uint32_t match_len;             // S_DIST: the length decoded by S_SYM
   uint32_t copy_len, copy_dist;   // LZ77 copy in flight (S_STORED: raw bytes left, in copy_len)
-  uint32_t pend_lo, pend_hi;      // its next (up to) 8 source bytes, requested a step ahead
+  // its next (up to) 16 source bytes, requested a step ahead.  16 rather than 8: one step (and one
+  // 64-byte sector each way) per match up to 16 bytes; +11 % on config 5 (profiles/r02/README.md)
+  uint32_t pend_lo, pend_hi, pend_2 = 0, pend_3 = 0;
+  constexpr uint32_t kChunk = 16;
   uint32_t lit_lo, lit_hi, lit_n; // up to eight literals decoded but not stored yet (they end at opos)
   out = P.out;
   out_cap = 0;
@@ -1049,7 +1053,7 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
     uint32_t k = 0;  // bytes of the copy in flight that go out this step
     if (state != S_STORED && copy_len != 0) {
       k = copy_len < copy_dist ? copy_len : copy_dist;  // source bytes that already exist
-      if (k > 8u) k = 8u;
+      if (k > kChunk) k = kChunk;
     }
     const bool last_chunk = copy_len == k;
     const uint32_t copy_dst = opos;  // where phase (2) stores those k bytes
@@ -1157,7 +1161,27 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
     // right after the final ones and overwrites the rest, and nothing reads them before that.
     if (k != 0) {
       uint8_t *dst = out + copy_dst;
-      if (copy_dst + 8u <= out_cap) {
+      if (copy_dst + 16u <= out_cap) {
+        const uint4 v4 = make_uint4(pend_lo, pend_hi, pend_2, pend_3);
+        __builtin_memcpy(dst, &v4, 16);
+      } else if (k & 8u) {  // (only near the end of the slot)
+        const uint64_t v = ((uint64_t)pend_hi << 32) | pend_lo;
+        __builtin_memcpy(dst, &v, 8);
+        dst += 8;
+        uint32_t w = pend_2;
+        if (k & 4u) {
+          __builtin_memcpy(dst, &w, 4);
+          dst += 4;
+          w = pend_3;
+        }
+        if (k & 2u) {
+          const uint16_t h = (uint16_t)w;
+          __builtin_memcpy(dst, &h, 2);
+          dst += 2;
+          w >>= 16;
+        }
+        if (k & 1u) *dst = (uint8_t)w;
+      } else if (copy_dst + 8u <= out_cap) {
         const uint64_t v = ((uint64_t)pend_hi << 32) | pend_lo;
         __builtin_memcpy(dst, &v, 8);
       } else {
@@ -1202,16 +1226,26 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
     }
     if (state != S_STORED && copy_len != 0) {
       const uint8_t *src = out + opos - copy_dist;
-      if (opos - copy_dist + 8u <= out_cap) {  // the 8-byte read stays inside this stream's slot
-        pend_lo = ld32g(src);
-        pend_hi = ld32g(src + 4);
+      // (streaming loads: the history is not read again soon, and the lines they would displace
+      // in L2 are the output lines the lanes are still filling)
+      if (opos - copy_dist + 16u <= out_cap) {  // the read stays inside this stream's slot
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        typedef u32x4 u128u __attribute__((aligned(1)));
+        const u32x4 hv = __builtin_nontemporal_load(reinterpret_cast<const u128u *>(src));
+        pend_lo = hv.x;
+        pend_hi = hv.y;
+        pend_2 = hv.z;
+        pend_3 = hv.w;
       } else {
         uint32_t n = copy_len < copy_dist ? copy_len : copy_dist;
-        if (n > 8u) n = 8u;
-        uint64_t v = 0;
-        for (uint32_t i = 0; i < n; ++i) v |= (uint64_t)src[i] << (8 * i);
+        if (n > 16u) n = 16u;
+        uint64_t v = 0, v2 = 0;
+        for (uint32_t i = 0; i < n && i < 8u; ++i) v |= (uint64_t)src[i] << (8 * i);
+        for (uint32_t i = 8; i < n; ++i) v2 |= (uint64_t)src[i] << (8 * (i - 8));
         pend_lo = (uint32_t)v;
         pend_hi = (uint32_t)(v >> 32);
+        pend_2 = (uint32_t)v2;
+        pend_3 = (uint32_t)(v2 >> 32);
       }
     }
   }
