@@ -1,7 +1,9 @@
 """Reduce the two PMC passes of tools/traffic_collect.sh: per kernel FETCH_SIZE / WRITE_SIZE (KB,
 mean over dispatches) -> HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 reports
 half of coalesced read bytes in FETCH_SIZE: MI355X_MICROARCH.md, HBM section; confirmed in round 1 on
-a kernel that reads exactly what it writes).  Prints one JSON object."""
+a kernel that reads exactly what it writes).  The guest match finder is the exception: its fetches
+are single 64-B sectors (2-byte table gathers), which FETCH_SIZE reports in full, so its raw value
+is used.  Prints one JSON object."""
 import collections, csv, glob, json, os, sys
 
 d, n, blen, K = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
@@ -27,8 +29,11 @@ clen = normal["config"]["compressed_bytes_per_gpu"]
 kern = {}
 for k in sorted(set(fs) | set(ws)):
     if "flate::" in k:
-        kern[k] = {"FETCH_SIZE_KB_raw": fs.get(k, 0.0), "WRITE_SIZE_KB": ws.get(k, 0.0),
-                   "hbm_bytes_per_launch": int((2 * fs.get(k, 0.0) + ws.get(k, 0.0)) * 1024)}
+        raw = "lz77_guest_kernel" in k
+        kern[k] = {"FETCH_SIZE_bytes_raw": int(fs.get(k, 0.0) * 1024), "WRITE_SIZE_bytes": int(ws.get(k, 0.0) * 1024),
+                   "read_rule": "raw: single 64-B sector requests (2-byte table gathers)" if raw else
+                                "x2: coalesced wide reads (gfx950 FETCH_SIZE reports half)",
+                   "hbm_bytes_per_launch": int(((1 if raw else 2) * fs.get(k, 0.0) + ws.get(k, 0.0)) * 1024)}
 lz = sum(v["hbm_bytes_per_launch"] for k, v in kern.items() if "lz77" in k)
 step = sum(v["hbm_bytes_per_launch"] for v in kern.values())
 algo = n * blen + clen
@@ -40,4 +45,7 @@ print(json.dumps({
     "hbm_bytes_per_launch": lz, "lz77_over_algorithmic": round(lz / algo, 3),
     "whole_step_hbm_bytes": step, "whole_step_over_algorithmic": round(step / algo, 3),
     "kernels": kern,
-    "note": "FETCH_SIZE x2 (gfx950 coalesced-read correction) + WRITE_SIZE, KB -> B; separate --pmc passes"}, indent=1))
+    "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/traffic_collect.sh); "
+            "the counters sit at the L2's memory side, Infinity-Cache hits included (MI355X_MICROARCH.md), so for "
+            "the guest kernel -- whose tables overflow the 4 MiB L2 of their XCD -- most of these bytes are "
+            "L2 <-> Infinity Cache traffic, not HBM"}, indent=1))
