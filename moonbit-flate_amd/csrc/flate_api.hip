@@ -41,7 +41,7 @@ struct flate_hip_ctx {
   // grow-only scratch
   DevBuf d_in, d_out, d_in_off, d_chunk_base, d_ids16, d_ids32, d_matches, d_nmatch, d_ntok;
   DevBuf d_slot_off, d_out_len, d_out_off, d_status;
-  DevBuf d_blk_base, d_blk_hist, d_blk_cl, d_blk_hdr, d_blk_meta;
+  DevBuf d_blk_base, d_blk_hist, d_blk_cl, d_blk_hdr, d_blk_meta, d_tile_meta;
   DevBuf d_istatus, d_ierr, d_debug, d_gtables, d_queue;
   hipStream_t guest_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -435,7 +435,7 @@ void flate_hip_destroy(flate_hip_ctx *c) {
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
   for (DevBuf *b : {&c->scan_tab, &c->d_in, &c->d_out, &c->d_in_off, &c->d_chunk_base, &c->d_ids16,
                     &c->d_ids32, &c->d_matches, &c->d_nmatch, &c->d_ntok, &c->d_blk_base,
-                    &c->d_blk_hist, &c->d_blk_cl, &c->d_blk_hdr, &c->d_blk_meta, &c->d_slot_off, &c->d_out_len, &c->d_out_off, &c->d_status, &c->d_istatus,
+                    &c->d_blk_hist, &c->d_blk_cl, &c->d_blk_hdr, &c->d_blk_meta, &c->d_tile_meta, &c->d_slot_off, &c->d_out_len, &c->d_out_off, &c->d_status, &c->d_istatus,
                     &c->d_ierr, &c->d_debug, &c->d_gtables, &c->d_queue})
     release(*b);
   for (auto &e : c->ev)
@@ -548,6 +548,7 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
   if ((rc = ensure(c, c->d_blk_cl, nb * 320 * 4))) return rc;
   if ((rc = ensure(c, c->d_blk_hdr, nb * 704 * 4))) return rc;
   if ((rc = ensure(c, c->d_blk_meta, nb * 16))) return rc;
+  if ((rc = ensure(c, c->d_tile_meta, nb * 16384))) return rc;  // 256 tiles x 64 lanes per block
   if ((rc = ensure(c, c->d_out_len, (size_t)n * 8 + 8))) return rc;
   if ((rc = ensure(c, c->d_out_off, ((size_t)n + 1) * 8))) return rc;
   if (spliced) {
@@ -599,6 +600,7 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
   H.blk_cl = (uint32_t *)c->d_blk_cl.p;
   H.blk_hdr = (uint32_t *)c->d_blk_hdr.p;
   H.blk_meta = (uint4 *)c->d_blk_meta.p;
+  H.tile_meta = (uint8_t *)c->d_tile_meta.p;
   H.spliced = spliced ? 1u : 0u;
   H.stream_sum = spliced ? (uint64_t *)c->d_slot_off.p : nullptr;
   H.stream_bit = spliced ? (const uint64_t *)c->d_out_off.p : nullptr;

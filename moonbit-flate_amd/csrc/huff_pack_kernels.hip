@@ -13,7 +13,8 @@
 //   huff_hist_kernel  index_tokens: per-block symbol histograms          (~2 KiB LDS)
 //   huff_code_kernel  code construction, header, exact block bit sizes   (~15 KiB LDS, short)
 //   huff_pack_kernel  write_dynamic_header + write_tokens, straight into the final
-//                     output at the offsets given by a scan of the exact sizes (~3 KiB LDS)
+//                     output at the offsets given by a scan of the exact sizes (~1.5 KiB LDS);
+//                     the token walk itself is handed over by huff_hist_kernel (tile_meta)
 // Everything that is a loop over tokens or symbols in the reference is a wave-parallel pass:
 //  * the token sequence is never materialised: each lane owns one input position of a
 //    64-byte tile and decides from the (sorted) match records whether it is a literal,
@@ -75,7 +76,6 @@ struct SharedHist {
 struct SharedPack {
   uint32_t lit_cl[288];
   uint32_t off_cl[32];
-  uint2 tile[kTile];
   uint32_t ring[kRing];
 };
 
@@ -190,17 +190,6 @@ FLATE_D void sink_emit_wide(BitSink &S, uint64_t lo, uint64_t hi, uint32_t nb, i
     S.flushed += 64;
   }
   __syncthreads();
-}
-
-// append nb bits to the (lo, hi) accumulator holding n bits so far
-FLATE_D void acc_append(uint64_t &lo, uint64_t &hi, uint32_t &n, uint64_t bits, uint32_t nb) {
-  if (n < 64u) {
-    lo |= bits << n;
-    if (n && n + nb > 64u) hi |= bits >> (64u - n);
-  } else {
-    hi |= bits << (n - 64u);
-  }
-  n += nb;
 }
 
 // flush(): pad with zero bits to a byte boundary (huffman-bit-writer.mbt:139-158)
@@ -392,7 +381,14 @@ struct TileTok {
   uint32_t lit_mask;  // bit k: position k is a literal
   int match_k;        // 0..3: a match starts at position k; -1: none
   uint32_t tok;       // its token
+  // What huff_pack_kernel needs to know about a lane's four positions, in one byte: the walk is
+  // done once, by huff_hist_kernel, and handed over through HuffParams::tile_meta (64 bytes per
+  // tile).  The j-th lane of a tile with bit 4 set starts the j-th match record of that tile.
+  // Positions after a match start are covered (matches are >= 4 long), so the literals of a lane
+  // all precede its match.
+  FLATE_D uint32_t pack() const { return lit_mask | (match_k >= 0 ? 0x10u | ((uint32_t)match_k << 5) : 0u); }
 };
+constexpr int kTileMetaPerBlock = 16384;  // 256 tiles (65535 positions) x 64 lanes
 
 struct Walker {
   const uint8_t *src;
@@ -673,8 +669,10 @@ __global__ __launch_bounds__(64) void huff_hist_kernel(HuffParams P) {
       const uint32_t chunk = g.chunk0 + b;
       Walker w = walker_init(src, P.matches + (uint64_t)chunk * kMatchCapPerChunk, P.chunk_nmatch[chunk],
                              n, lane);
+      uint8_t *tmeta = P.tile_meta + (uint64_t)gb * kTileMetaPerBlock;
       for (int P0 = 0; P0 < n; P0 += kTile) {
         const TileTok t = walk_tile(sh.tile, w, P0, lane);
+        tmeta[(P0 >> 2) + lane] = (uint8_t)t.pack();
         if (t.match_k >= 0) {
           const CodeBits lc = length_code_of((t.tok >> kLengthShift) & 0xffu);
           const CodeBits oc = offset_code_of(t.tok & ((1u << kLengthShift) - 1u));
@@ -875,46 +873,74 @@ __global__ __launch_bounds__(64) void huff_pack_kernel(HuffParams P) {
         const int i = base + 4 * lane;
         const uint32_t bt = w.bytes;
         w.bytes = load_bytes4(w, i + kTile);
-        uint64_t lo = 0, hi = 0;
+        uint64_t lo = 0;  // four codes of <= 15 bits
         uint32_t nb = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           if (i + k < n) {
             const uint32_t c = sh.lit_cl[(bt >> (8 * k)) & 0xffu];
-            acc_append(lo, hi, nb, c & 0xffffu, c >> 16);
+            lo |= (uint64_t)(c & 0xffffu) << nb;
+            nb += c >> 16;
           }
-        sink_emit_wide(S, lo, hi, nb, lane);
+        sink_emit_wide(S, lo, 0, nb, lane);
       }
     } else {
+      // The walk over the implied token sequence was done by huff_hist_kernel: per tile, one byte
+      // per lane (TileTok::pack) says which of the lane's four positions are literals and whether
+      // a match starts there; the lane's rank among the match lanes of the tile is its record.
+      // Everything a tile needs is loaded one tile ahead (its meta byte two ahead).
       const uint32_t chunk = g.chunk0 + b;
-      Walker w = walker_init(src, P.matches + (uint64_t)chunk * kMatchCapPerChunk, P.chunk_nmatch[chunk],
-                             n, lane);
-      for (int P0 = 0; P0 < n; P0 += kTile) {
-        const TileTok t = walk_tile(sh.tile, w, P0, lane);
+      const uint2 *recs = P.matches + (uint64_t)chunk * kMatchCapPerChunk;
+      const uint8_t *tmeta = P.tile_meta + (uint64_t)gb * kTileMetaPerBlock;
+      Walker w = walker_init(src, nullptr, 0u, n, lane);  // (input bytes only)
+      const int ntiles = (n + kTile - 1) / kTile;
+      uint32_t mp = 0;
+      auto tok_of = [&](uint32_t m) -> uint32_t {
+        const bool has = (m & 0x10u) != 0;
+        const uint64_t B = __ballot(has);
+        uint32_t tok = 0;
+        if (has) tok = recs[mp + (uint32_t)__popcll(B & ((1ull << lane) - 1ull))].y;
+        mp += (uint32_t)__popcll(B);
+        return tok;
+      };
+      uint32_t m_cur = tmeta[lane];
+      uint32_t tok_cur = tok_of(m_cur);
+      uint32_t m_next = ntiles > 1 ? tmeta[64 + lane] : 0u;
+      for (int t = 0; t < ntiles; ++t) {
+        const uint32_t bt = w.bytes;
+        w.bytes = load_bytes4(w, (t + 1) * kTile + 4 * lane);
+        const uint32_t tok_next = tok_of(m_next);
+        const uint32_t m_next2 = t + 2 < ntiles ? tmeta[(t + 2) * 64 + lane] : 0u;
         uint64_t lo = 0, hi = 0;
         uint32_t nb = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if ((t.lit_mask >> k) & 1u) {
-            const uint32_t c = sh.lit_cl[(t.bytes >> (8 * k)) & 0xffu];
-            acc_append(lo, hi, nb, c & 0xffffu, c >> 16);
-          } else if (t.match_k == k) {
-            const CodeBits lc = length_code_of((t.tok >> kLengthShift) & 0xffu);
-            const CodeBits oc = offset_code_of(t.tok & ((1u << kLengthShift) - 1u));
-            const uint32_t c1 = sh.lit_cl[kLengthCodesStart + lc.code];
-            const uint32_t c2 = sh.off_cl[oc.code];
-            uint64_t bits = c1 & 0xffffu;
-            uint32_t mb = c1 >> 16;
-            bits |= (uint64_t)lc.extra << mb;
-            mb += lc.nextra;
-            bits |= (uint64_t)(c2 & 0xffffu) << mb;
-            mb += c2 >> 16;
-            bits |= (uint64_t)oc.extra << mb;
-            mb += oc.nextra;
-            acc_append(lo, hi, nb, bits, mb);
+        for (int k = 0; k < 4; ++k)
+          if ((m_cur >> k) & 1u) {  // at most three when a match follows: <= 45 bits
+            const uint32_t c = sh.lit_cl[(bt >> (8 * k)) & 0xffu];
+            lo |= (uint64_t)(c & 0xffffu) << nb;
+            nb += c >> 16;
           }
+        if (m_cur & 0x10u) {
+          const CodeBits lc = length_code_of((tok_cur >> kLengthShift) & 0xffu);
+          const CodeBits oc = offset_code_of(tok_cur & ((1u << kLengthShift) - 1u));
+          const uint32_t c1 = sh.lit_cl[kLengthCodesStart + lc.code];
+          const uint32_t c2 = sh.off_cl[oc.code];
+          uint64_t bits = c1 & 0xffffu;
+          uint32_t mb = c1 >> 16;
+          bits |= (uint64_t)lc.extra << mb;
+          mb += lc.nextra;
+          bits |= (uint64_t)(c2 & 0xffffu) << mb;
+          mb += c2 >> 16;
+          bits |= (uint64_t)oc.extra << mb;
+          mb += oc.nextra;  // <= 48
+          hi = nb ? bits >> (64u - nb) : 0ull;
+          lo |= bits << nb;
+          nb += mb;
         }
         sink_emit_wide(S, lo, hi, nb, lane);
+        m_cur = m_next;
+        tok_cur = tok_next;
+        m_next = m_next2;
       }
     }
     const uint32_t eob = sh.lit_cl[kEndBlockMarker];
