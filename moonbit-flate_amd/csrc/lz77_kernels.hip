@@ -365,7 +365,7 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
         int a = 0;
         for (;;) {  // events inside this batch
           // Chase the fast events: x = ev[a]; visit a; a = next[a]; until an event needs the
-          // general path or asks to stop.  Hand-written: the whole step is 9 scalar
+          // general path or asks to stop.  Hand-written: a step is 9 scalar
           // instructions (the compiler's version of this loop cost ~290 cycles per match).
           uint32_t x, tmp;
           uint64_t VIS = 0, MFl = 0;
@@ -373,6 +373,19 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
           STAMP(tc0);
           asm volatile(
               "1:\n\t"
+              "s_nop 1\n\t"
+              "v_readlane_b32 %[x], %[ev], %[a]\n\t"
+              "s_nop 3\n\t"
+              "s_bitcmp1_b32 %[x], 16\n\t"
+              "s_cbranch_scc1 2f\n\t"
+              "s_bitset1_b64 %[vis], %[a]\n\t"
+              "s_and_b32 %[t], %[x], 0x7f\n\t"
+              "s_bitset1_b64 %[mf], %[t]\n\t"
+              "s_lshr_b32 %[a], %[x], 24\n\t"
+              "s_bitcmp1_b32 %[x], 18\n\t"
+              "s_cbranch_scc1 2f\n\t"
+              // (second copy: one taken branch per two events; the lane select written by s_lshr
+              // needs its four wait states here too)
               "s_nop 1\n\t"
               "v_readlane_b32 %[x], %[ev], %[a]\n\t"
               "s_nop 3\n\t"
