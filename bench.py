@@ -567,7 +567,8 @@ def extra_legs(args, env):
                 raise SystemExit("host-pointer call produced a different size")
             extra["end_to_end_host_pointers"] = {
                 "value": round(n * blen / min(ts) / 2**30, 2), "unit": "GiB/s", "step_ms": summarize(ts),
-                "note": "same workload, input and output in pageable host memory: the call copies 1 GiB in and "
+                "note": "same workload, input and output in pageable host memory (copies pipelined with the "
+                        "compression over groups of streams): the call copies 1 GiB in and "
                         "%.2f GiB out over PCIe (not the headline value)" % (clen / 2**30)}
         del host, d_in
     extra["other_inputs_16384x65536"] = others

@@ -11,7 +11,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "flate_kernels.h"
@@ -78,6 +81,11 @@ struct flate_hip_ctx {
   uint32_t last_count[2] = {0, 0};   // queue lengths of the last persistent launches (16-bit, multi)
   uint32_t queue_init = 0;
   uint32_t debug_chunks = 0;
+  // Host-pointer calls of the batch encoder: the batch is cut into host_groups groups of streams
+  // and group g is compressed while group g+1 is copied in and the output of group g-1 is copied
+  // out (two copy threads on two non-blocking streams).  0 = one copy in, compress, one copy out.
+  int host_groups = 4;
+  hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
 };
 
 namespace {
@@ -433,6 +441,8 @@ void flate_hip_destroy(flate_hip_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+  if (c->h2d_stream) (void)hipStreamDestroy(c->h2d_stream);
+  if (c->d2h_stream) (void)hipStreamDestroy(c->d2h_stream);
   for (DevBuf *b : {&c->scan_tab, &c->d_in, &c->d_out, &c->d_in_off, &c->d_chunk_base, &c->d_ids16,
                     &c->d_ids32, &c->d_matches, &c->d_nmatch, &c->d_ntok, &c->d_blk_base,
                     &c->d_blk_hist, &c->d_blk_cl, &c->d_blk_hdr, &c->d_blk_meta, &c->d_tile_meta, &c->d_slot_off, &c->d_out_len, &c->d_out_off, &c->d_status, &c->d_istatus,
@@ -474,6 +484,8 @@ int flate_hip_set_option(flate_hip_ctx *c, const char *name, int64_t value) {
     c->inflate_simt_min = (uint32_t)value;
   } else if (k == "resident_blocks" && value > 0 && value <= 65536) {
     c->resident_blocks = (uint32_t)value;
+  } else if (k == "host_pipeline_groups" && value >= 0 && value <= 64) {
+    c->host_groups = (int)value;
   } else if (k == "profile_split_streams" && value >= 0 && value <= 0x7fffffff) {
     c->profile_split = (uint32_t)value;
   } else if (k == "window_units" && (value == 0 || value == 1)) {
@@ -712,6 +724,132 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
   return collect_timing(c, used);
 }
 
+// Host-pointer batch, pipelined over groups of streams (flate_hip_ctx::host_groups).  The streams
+// are independent, so the bytes are those of one call over the whole batch.
+static int deflate_host_pipelined(flate_hip_ctx *c, const uint8_t *in, const uint64_t *in_off, uint32_t n,
+                                  uint8_t *out, uint64_t out_cap, uint64_t *out_off, uint32_t flags,
+                                  uint32_t G) {
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint64_t in_bytes = in_off[n];
+  int rc;
+  if ((rc = ensure(c, c->d_in, in_bytes + 16))) return rc;
+  if ((rc = ensure(c, c->d_out, out_cap + 16))) return rc;
+  if (!c->h2d_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking));
+  if (!c->d2h_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
+  // group boundaries: equal stream counts (the streams of one batch are of similar size)
+  std::vector<uint32_t> lo(G + 1);
+  for (uint32_t g = 0; g <= G; ++g) lo[g] = (uint32_t)((uint64_t)n * g / G);
+
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<int> in_ready(G, 0);                 // 1 = on the device, -1 = copy failed
+  std::vector<int> out_ready(G, 0);                // 1 = compressed (out_at / out_bytes valid), -1 = give up
+  std::vector<uint64_t> out_at(G, 0), out_bytes(G, 0);
+  std::string h2d_err, d2h_err;
+  bool abort_in = false;
+
+  const int device = c->device;
+  uint8_t *d_in = (uint8_t *)c->d_in.p, *d_out = (uint8_t *)c->d_out.p;
+  hipStream_t s_in = c->h2d_stream, s_out = c->d2h_stream;
+  std::thread t_in([&] {
+    (void)hipSetDevice(device);
+    for (uint32_t g = 0; g < G; ++g) {
+      {
+        std::lock_guard<std::mutex> l(mu);
+        if (abort_in) return;
+      }
+      const uint64_t a = in_off[lo[g]], b = in_off[lo[g + 1]];
+      hipError_t e = hipSuccess;
+      if (b > a) e = hipMemcpyAsync(d_in + a, in + a, b - a, hipMemcpyHostToDevice, s_in);
+      if (e == hipSuccess) e = hipStreamSynchronize(s_in);
+      std::lock_guard<std::mutex> l(mu);
+      if (e != hipSuccess) h2d_err = std::string("host-to-device copy: ") + hipGetErrorString(e);
+      in_ready[g] = e == hipSuccess ? 1 : -1;
+      cv.notify_all();
+      if (e != hipSuccess) return;
+    }
+  });
+  std::thread t_out([&] {
+    (void)hipSetDevice(device);
+    for (uint32_t g = 0; g < G; ++g) {
+      uint64_t at, nb;
+      {
+        std::unique_lock<std::mutex> l(mu);
+        cv.wait(l, [&] { return out_ready[g] != 0; });
+        if (out_ready[g] < 0) return;
+        at = out_at[g];
+        nb = out_bytes[g];
+      }
+      hipError_t e = hipSuccess;
+      if (nb) e = hipMemcpyAsync(out + at, d_out + at, nb, hipMemcpyDeviceToHost, s_out);
+      if (e == hipSuccess) e = hipStreamSynchronize(s_out);
+      if (e != hipSuccess) {
+        std::lock_guard<std::mutex> l(mu);
+        d2h_err = std::string("device-to-host copy: ") + hipGetErrorString(e);
+        return;
+      }
+    }
+  });
+
+  float stage_sum[FLATE_HIP_STAGE_COUNT] = {0, 0, 0, 0};
+  std::vector<uint64_t> goff, gin;
+  uint64_t at = 0;
+  rc = FLATE_HIP_OK;
+  out_off[0] = 0;
+  for (uint32_t g = 0; g < G && rc == FLATE_HIP_OK; ++g) {
+    {
+      std::unique_lock<std::mutex> l(mu);
+      cv.wait(l, [&] { return in_ready[g] != 0; });
+      if (in_ready[g] < 0) {
+        c->hip_err = h2d_err;
+        rc = FLATE_HIP_E_HIP;
+        break;
+      }
+    }
+    const uint32_t cnt = lo[g + 1] - lo[g];
+    if (cnt == 0) {
+      std::lock_guard<std::mutex> l(mu);
+      out_at[g] = at;
+      out_bytes[g] = 0;
+      out_ready[g] = 1;
+      cv.notify_all();
+      continue;
+    }
+    gin.resize((size_t)cnt + 1);
+    goff.resize((size_t)cnt + 1);
+    const uint64_t base = in_off[lo[g]];
+    for (uint32_t i = 0; i <= cnt; ++i) gin[i] = in_off[lo[g] + i] - base;
+    rc = deflate_common(c, d_in + base, gin.data(), cnt, d_out + at, out_cap - at, goff.data(),
+                        flags | FLATE_HIP_DEVICE_PTRS, false, nullptr);
+    if (rc != FLATE_HIP_OK) break;
+    for (uint32_t i = 1; i <= cnt; ++i) out_off[lo[g] + i] = at + goff[i];
+    for (int k = 0; k < FLATE_HIP_STAGE_COUNT; ++k) stage_sum[k] += c->stage_ms[k];
+    {
+      std::lock_guard<std::mutex> l(mu);
+      out_at[g] = at;
+      out_bytes[g] = goff[cnt];
+      out_ready[g] = 1;
+      cv.notify_all();
+    }
+    at += goff[cnt];
+  }
+  {  // release the copy threads whatever happened
+    std::lock_guard<std::mutex> l(mu);
+    abort_in = true;
+    for (uint32_t g = 0; g < G; ++g)
+      if (out_ready[g] == 0) out_ready[g] = -1;
+    cv.notify_all();
+  }
+  t_in.join();
+  t_out.join();
+  if (rc == FLATE_HIP_OK && !d2h_err.empty()) {
+    c->hip_err = d2h_err;
+    rc = FLATE_HIP_E_HIP;
+  }
+  for (int k = 0; k < FLATE_HIP_STAGE_COUNT; ++k) c->stage_ms[k] = stage_sum[k];
+  return rc;
+}
+
 extern "C" {
 
 int flate_hip_deflate_fast_batch(flate_hip_ctx *c, const uint8_t *in, const uint64_t *in_off,
@@ -722,6 +860,18 @@ int flate_hip_deflate_fast_batch(flate_hip_ctx *c, const uint8_t *in, const uint
   if (n == 0) {
     out_off[0] = 0;
     return FLATE_HIP_OK;
+  }
+  // host pointers and a batch large enough that every group still fills the persistent launch
+  if (!(flags & FLATE_HIP_DEVICE_PTRS) && c->host_groups > 1 && in_off[n] >= (64ull << 20)) {
+    uint32_t G = (uint32_t)c->host_groups;
+    const uint32_t per = c->guest_min > 0 ? c->guest_min : 1u;
+    if (n / per < G) G = n / per;
+    if (G > 1) {
+      StagePlan pl;  // validate the whole index first (the same checks as the one-call path)
+      const int rc = make_plan(in_off, n, pl);
+      if (rc) return rc;
+      return deflate_host_pipelined(c, in, in_off, n, out, out_cap, out_off, flags, G);
+    }
   }
   return deflate_common(c, in, in_off, n, out, out_cap, out_off, flags, false, nullptr);
 }

@@ -266,3 +266,30 @@ def test_overlapped_entropy_stage_is_bit_exact(oracle):
                 assert a.size == b.size and np.array_equal(a, b), ("multi", sub, units, i)
     finally:
         e.close()
+
+
+def test_host_pointer_pipeline_matches_single_pass(oracle):
+    # host-pointer calls on large batches are pipelined over groups of streams (option
+    # host_pipeline_groups): same bytes and the same index as one pass, and as the oracle
+    n, blen = 8192 + 37, 65536 - 3
+    host = flate.synth("text", n, blen)
+    off = flate.uniform_offsets(n, blen)
+    e = flate.FlateEngine(0)
+    try:
+        e.set_option("host_pipeline_groups", 0)
+        c0, o0 = e.deflate_batch(host, off)
+        for groups in (2, 3):
+            e.set_option("host_pipeline_groups", groups)
+            c1, o1 = e.deflate_batch(host, off)
+            assert np.array_equal(np.asarray(o0), np.asarray(o1)), groups
+            total = int(o0[-1])
+            assert np.array_equal(np.asarray(c0)[:total], np.asarray(c1)[:total]), groups
+        c = np.asarray(c1)
+        for i in range(0, n, 509):
+            assert bytes(c[int(o1[i]):int(o1[i + 1])]) == oracle.deflate(host[i * blen:(i + 1) * blen]), i
+        # an output buffer that is too small is still reported
+        e.set_option("host_pipeline_groups", 2)
+        with pytest.raises(flate.FlateError):
+            e.deflate_batch(host, off, out_cap=int(o0[-1]) // 2)
+    finally:
+        e.close()
