@@ -497,6 +497,26 @@ def bench_inflate(args, env, d_in, in_off, n, blen, host=None, steps=None, warmu
                       % (ns, n, ns * blen >> 20, cores, cdt),
             "host": info,
         }
+    host_leg = None
+    if getattr(args, "inflate_host_leg", False) and not args.spliced and world == 1:
+        # the same call with pageable host buffers (copies pipelined with the decoding over groups of
+        # streams): the PCIe-inclusive rate, never the headline
+        h_comp = comp[:int(coff[-1])].cpu().numpy()
+        h_out = np.empty(n * blen, dtype=np.uint8)
+        ts = []
+        for _ in range(2):
+            t1 = time.perf_counter()
+            _, _, h_len, h_st, _ = eng.inflate_batch(h_comp, coff, sizes, out=h_out)
+            ts.append(time.perf_counter() - t1)
+        if int(h_st.any()) or int((h_len != blen).any()):
+            raise SystemExit("host-pointer inflate failed")
+        for i in range(0, n, 4099):
+            if not np.array_equal(h_out[i * blen:(i + 1) * blen], d_in[i * blen:(i + 1) * blen].cpu().numpy()):
+                raise SystemExit("host-pointer inflate: output != input at stream %d" % i)
+        host_leg = {"value": round(n * blen / min(ts) / 2**30, 2), "unit": "GiB/s", "step_ms": summarize(ts),
+                    "note": "same workload, input and output in pageable host memory: %.2f GiB in and %.2f GiB "
+                            "out over PCIe (not the headline value)" % (int(coff[-1]) / 2**30, n * blen / 2**30)}
+        del h_comp, h_out
     clen = int(coff[-1])
     k_ms = ms / steps
     achieved = (n * blen + clen) / (k_ms * 1e-3) / 1e9
@@ -517,7 +537,8 @@ def bench_inflate(args, env, d_in, in_off, n, blen, host=None, steps=None, warmu
                      "achieved": round(achieved, 2),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                      "traffic": traffic},
-        "cpu_baseline": cpu_baseline}
+        "cpu_baseline": cpu_baseline,
+        **({"end_to_end_host_pointers": host_leg} if host_leg else {})}
 
 
 def extra_legs(args, env):
@@ -630,9 +651,11 @@ def extra_legs(args, env):
     in_off = flate.uniform_offsets(n, blen)
     ia = argparse.Namespace(**vars(args))
     ia.spliced, ia.no_cpu_baseline, ia.kind = False, True, "text"
+    ia.inflate_host_leg = True
     r = bench_inflate(ia, env, d_in, in_off, n, blen, steps=3, warmup=1)
     extra["config5_inflate_8GiB"] = {k: r[k] for k in ("metric", "value", "unit", "steps", "ms_per_step",
-                                                       "config", "roofline")}
+                                                       "config", "roofline", "end_to_end_host_pointers")
+                                     if k in r}
     return extra
 
 

@@ -67,8 +67,9 @@ int flate_hip_set_stream(flate_hip_ctx *ctx, void *hip_stream);
  *   "window_units"       1 (default): multi-window streams of a persistent launch are scheduled one
  *                        65535-byte window at a time (a stream's table rests in global memory
  *                        between its windows); 0: one block keeps a stream from start to end
- *   "host_pipeline_groups"  host-pointer calls of flate_hip_deflate_fast_batch on >= 64 MiB: the batch
- *                        is cut into this many groups of streams (each at least guest_min_streams) and
+ *   "host_pipeline_groups"  host-pointer calls of flate_hip_deflate_fast_batch / flate_hip_inflate_batch
+ *                        on >= 64 MiB: the batch is cut into this many groups of streams (each at
+ *                        least guest_min_streams, for inflate 16384) and
  *                        group g is compressed while group g+1 is copied in and the output of g-1
  *                        is copied out (default 4; 0 or 1: copy in, compress, copy out)
  *   "overlap_sub_batches"  > 0: the entropy kernels of every sub-batch (queue order) run on a

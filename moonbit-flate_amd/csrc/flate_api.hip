@@ -724,128 +724,146 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
   return collect_timing(c, used);
 }
 
-// Host-pointer batch, pipelined over groups of streams (flate_hip_ctx::host_groups).  The streams
-// are independent, so the bytes are those of one call over the whole batch.
+// ---- host-pointer batches, pipelined over groups of streams (flate_hip_ctx::host_groups) ----
+// Two copy threads beside the calling thread: one brings the groups' input to the device in
+// order, the other takes every group's output back as soon as the caller posts it.  Each uses its
+// own non-blocking HIP stream, so the copies run beside the kernels of the group in between.
+namespace {
+struct CopyJob {
+  void *dst;
+  const void *src;
+  size_t bytes;
+};
+class CopyPipe {
+ public:
+  CopyPipe(int device, hipStream_t s_in, hipStream_t s_out, std::vector<CopyJob> in_jobs, size_t n_out)
+      : in_ready_(in_jobs.size(), 0), out_state_(n_out, 0), out_jobs_(n_out) {
+    t_in_ = std::thread([this, device, s_in, in_jobs] {
+      (void)hipSetDevice(device);
+      for (size_t g = 0; g < in_jobs.size(); ++g) {
+        {
+          std::lock_guard<std::mutex> l(mu_);
+          if (stop_) return;
+        }
+        const bool ok = run(in_jobs[g], hipMemcpyHostToDevice, s_in, "host-to-device copy: ");
+        std::lock_guard<std::mutex> l(mu_);
+        in_ready_[g] = ok ? 1 : -1;
+        cv_.notify_all();
+        if (!ok) return;
+      }
+    });
+    t_out_ = std::thread([this, device, s_out, n_out] {
+      (void)hipSetDevice(device);
+      for (size_t g = 0; g < n_out; ++g) {
+        CopyJob j;
+        {
+          std::unique_lock<std::mutex> l(mu_);
+          cv_.wait(l, [&] { return out_state_[g] != 0; });
+          if (out_state_[g] < 0) return;
+          j = out_jobs_[g];
+        }
+        if (!run(j, hipMemcpyDeviceToHost, s_out, "device-to-host copy: ")) return;
+      }
+    });
+  }
+  // blocks until group g's input is on the device; false = its copy failed
+  bool wait_in(size_t g) {
+    std::unique_lock<std::mutex> l(mu_);
+    cv_.wait(l, [&] { return in_ready_[g] != 0; });
+    return in_ready_[g] > 0;
+  }
+  void post_out(size_t g, CopyJob j) {
+    std::lock_guard<std::mutex> l(mu_);
+    out_jobs_[g] = j;
+    out_state_[g] = 1;
+    cv_.notify_all();
+  }
+  // ends both threads (outputs not posted yet are dropped) and returns the first copy error
+  std::string finish() {
+    {
+      std::lock_guard<std::mutex> l(mu_);
+      stop_ = true;
+      for (auto &st : out_state_)
+        if (st == 0) st = -1;
+      cv_.notify_all();
+    }
+    if (t_in_.joinable()) t_in_.join();
+    if (t_out_.joinable()) t_out_.join();
+    return err_;
+  }
+  ~CopyPipe() { (void)finish(); }
+
+ private:
+  bool run(const CopyJob &j, hipMemcpyKind kind, hipStream_t s, const char *what) {
+    hipError_t e = hipSuccess;
+    if (j.bytes) e = hipMemcpyAsync(j.dst, j.src, j.bytes, kind, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) return true;
+    std::lock_guard<std::mutex> l(mu_);
+    if (err_.empty()) err_ = std::string(what) + hipGetErrorString(e);
+    return false;
+  }
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::vector<int> in_ready_, out_state_;  // 0 pending, 1 done / posted, -1 failed / dropped
+  std::vector<CopyJob> out_jobs_;
+  std::string err_;
+  bool stop_ = false;
+  std::thread t_in_, t_out_;
+};
+
+int host_pipe_streams(flate_hip_ctx *c) {
+  if (!c->h2d_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking));
+  if (!c->d2h_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
+  return FLATE_HIP_OK;
+}
+}  // namespace
+
+// The streams are independent, so the bytes are those of one call over the whole batch.
 static int deflate_host_pipelined(flate_hip_ctx *c, const uint8_t *in, const uint64_t *in_off, uint32_t n,
                                   uint8_t *out, uint64_t out_cap, uint64_t *out_off, uint32_t flags,
                                   uint32_t G) {
   HIP_TRY(c, hipSetDevice(c->device));
-  const uint64_t in_bytes = in_off[n];
   int rc;
-  if ((rc = ensure(c, c->d_in, in_bytes + 16))) return rc;
+  if ((rc = ensure(c, c->d_in, in_off[n] + 16))) return rc;
   if ((rc = ensure(c, c->d_out, out_cap + 16))) return rc;
-  if (!c->h2d_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking));
-  if (!c->d2h_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
-  // group boundaries: equal stream counts (the streams of one batch are of similar size)
-  std::vector<uint32_t> lo(G + 1);
-  for (uint32_t g = 0; g <= G; ++g) lo[g] = (uint32_t)((uint64_t)n * g / G);
-
-  std::mutex mu;
-  std::condition_variable cv;
-  std::vector<int> in_ready(G, 0);                 // 1 = on the device, -1 = copy failed
-  std::vector<int> out_ready(G, 0);                // 1 = compressed (out_at / out_bytes valid), -1 = give up
-  std::vector<uint64_t> out_at(G, 0), out_bytes(G, 0);
-  std::string h2d_err, d2h_err;
-  bool abort_in = false;
-
-  const int device = c->device;
+  if ((rc = host_pipe_streams(c))) return rc;
   uint8_t *d_in = (uint8_t *)c->d_in.p, *d_out = (uint8_t *)c->d_out.p;
-  hipStream_t s_in = c->h2d_stream, s_out = c->d2h_stream;
-  std::thread t_in([&] {
-    (void)hipSetDevice(device);
-    for (uint32_t g = 0; g < G; ++g) {
-      {
-        std::lock_guard<std::mutex> l(mu);
-        if (abort_in) return;
-      }
-      const uint64_t a = in_off[lo[g]], b = in_off[lo[g + 1]];
-      hipError_t e = hipSuccess;
-      if (b > a) e = hipMemcpyAsync(d_in + a, in + a, b - a, hipMemcpyHostToDevice, s_in);
-      if (e == hipSuccess) e = hipStreamSynchronize(s_in);
-      std::lock_guard<std::mutex> l(mu);
-      if (e != hipSuccess) h2d_err = std::string("host-to-device copy: ") + hipGetErrorString(e);
-      in_ready[g] = e == hipSuccess ? 1 : -1;
-      cv.notify_all();
-      if (e != hipSuccess) return;
-    }
-  });
-  std::thread t_out([&] {
-    (void)hipSetDevice(device);
-    for (uint32_t g = 0; g < G; ++g) {
-      uint64_t at, nb;
-      {
-        std::unique_lock<std::mutex> l(mu);
-        cv.wait(l, [&] { return out_ready[g] != 0; });
-        if (out_ready[g] < 0) return;
-        at = out_at[g];
-        nb = out_bytes[g];
-      }
-      hipError_t e = hipSuccess;
-      if (nb) e = hipMemcpyAsync(out + at, d_out + at, nb, hipMemcpyDeviceToHost, s_out);
-      if (e == hipSuccess) e = hipStreamSynchronize(s_out);
-      if (e != hipSuccess) {
-        std::lock_guard<std::mutex> l(mu);
-        d2h_err = std::string("device-to-host copy: ") + hipGetErrorString(e);
-        return;
-      }
-    }
-  });
+  std::vector<uint32_t> lo(G + 1);  // equal stream counts (the streams of one batch are of similar size)
+  std::vector<CopyJob> in_jobs(G);
+  for (uint32_t g = 0; g <= G; ++g) lo[g] = (uint32_t)((uint64_t)n * g / G);
+  for (uint32_t g = 0; g < G; ++g)
+    in_jobs[g] = {d_in + in_off[lo[g]], in + in_off[lo[g]], (size_t)(in_off[lo[g + 1]] - in_off[lo[g]])};
+  CopyPipe pipe(c->device, c->h2d_stream, c->d2h_stream, in_jobs, G);
 
   float stage_sum[FLATE_HIP_STAGE_COUNT] = {0, 0, 0, 0};
   std::vector<uint64_t> goff, gin;
   uint64_t at = 0;
   rc = FLATE_HIP_OK;
   out_off[0] = 0;
-  for (uint32_t g = 0; g < G && rc == FLATE_HIP_OK; ++g) {
-    {
-      std::unique_lock<std::mutex> l(mu);
-      cv.wait(l, [&] { return in_ready[g] != 0; });
-      if (in_ready[g] < 0) {
-        c->hip_err = h2d_err;
-        rc = FLATE_HIP_E_HIP;
-        break;
-      }
+  for (uint32_t g = 0; g < G; ++g) {
+    if (!pipe.wait_in(g)) {
+      rc = FLATE_HIP_E_HIP;
+      break;
     }
     const uint32_t cnt = lo[g + 1] - lo[g];
-    if (cnt == 0) {
-      std::lock_guard<std::mutex> l(mu);
-      out_at[g] = at;
-      out_bytes[g] = 0;
-      out_ready[g] = 1;
-      cv.notify_all();
-      continue;
-    }
     gin.resize((size_t)cnt + 1);
-    goff.resize((size_t)cnt + 1);
+    goff.assign((size_t)cnt + 1, 0);
     const uint64_t base = in_off[lo[g]];
     for (uint32_t i = 0; i <= cnt; ++i) gin[i] = in_off[lo[g] + i] - base;
-    rc = deflate_common(c, d_in + base, gin.data(), cnt, d_out + at, out_cap - at, goff.data(),
-                        flags | FLATE_HIP_DEVICE_PTRS, false, nullptr);
-    if (rc != FLATE_HIP_OK) break;
-    for (uint32_t i = 1; i <= cnt; ++i) out_off[lo[g] + i] = at + goff[i];
-    for (int k = 0; k < FLATE_HIP_STAGE_COUNT; ++k) stage_sum[k] += c->stage_ms[k];
-    {
-      std::lock_guard<std::mutex> l(mu);
-      out_at[g] = at;
-      out_bytes[g] = goff[cnt];
-      out_ready[g] = 1;
-      cv.notify_all();
+    if (cnt) {
+      rc = deflate_common(c, d_in + base, gin.data(), cnt, d_out + at, out_cap - at, goff.data(),
+                          flags | FLATE_HIP_DEVICE_PTRS, false, nullptr);
+      if (rc != FLATE_HIP_OK) break;
+      for (int k = 0; k < FLATE_HIP_STAGE_COUNT; ++k) stage_sum[k] += c->stage_ms[k];
     }
+    for (uint32_t i = 1; i <= cnt; ++i) out_off[lo[g] + i] = at + goff[i];
+    pipe.post_out(g, {out + at, d_out + at, (size_t)goff[cnt]});
     at += goff[cnt];
   }
-  {  // release the copy threads whatever happened
-    std::lock_guard<std::mutex> l(mu);
-    abort_in = true;
-    for (uint32_t g = 0; g < G; ++g)
-      if (out_ready[g] == 0) out_ready[g] = -1;
-    cv.notify_all();
-  }
-  t_in.join();
-  t_out.join();
-  if (rc == FLATE_HIP_OK && !d2h_err.empty()) {
-    c->hip_err = d2h_err;
-    rc = FLATE_HIP_E_HIP;
-  }
+  const std::string err = pipe.finish();
+  if (rc == FLATE_HIP_OK && !err.empty()) rc = FLATE_HIP_E_HIP;
+  if (rc == FLATE_HIP_E_HIP && c->hip_err.empty()) c->hip_err = err;
   for (int k = 0; k < FLATE_HIP_STAGE_COUNT; ++k) c->stage_ms[k] = stage_sum[k];
   return rc;
 }
@@ -1018,6 +1036,63 @@ static int inflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
   return FLATE_HIP_OK;
 }
 
+// Host-pointer inflate of independent streams, pipelined like deflate_host_pipelined: every
+// stream has its own input range and output slot, so a group is a contiguous range of both.
+static int inflate_host_pipelined(flate_hip_ctx *c, const uint8_t *in, const uint64_t *in_off, uint32_t n,
+                                  uint8_t *out, const uint64_t *out_off, uint64_t *out_len,
+                                  int32_t *status, int64_t *err_off, uint32_t flags, uint32_t G) {
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc;
+  if ((rc = ensure(c, c->d_in, in_off[n] + 16))) return rc;
+  if ((rc = ensure(c, c->d_out, out_off[n] + 16))) return rc;
+  if ((rc = host_pipe_streams(c))) return rc;
+  uint8_t *d_in = (uint8_t *)c->d_in.p, *d_out = (uint8_t *)c->d_out.p;
+  std::vector<uint32_t> lo(G + 1);
+  std::vector<CopyJob> in_jobs(G);
+  for (uint32_t g = 0; g <= G; ++g) lo[g] = (uint32_t)((uint64_t)n * g / G);
+  for (uint32_t g = 0; g < G; ++g)
+    in_jobs[g] = {d_in + in_off[lo[g]], in + in_off[lo[g]], (size_t)(in_off[lo[g + 1]] - in_off[lo[g]])};
+  CopyPipe pipe(c->device, c->h2d_stream, c->d2h_stream, in_jobs, G);
+  float stage_sum[FLATE_HIP_STAGE_COUNT] = {0, 0, 0, 0};
+  std::vector<uint64_t> gin, gout;
+  rc = FLATE_HIP_OK;
+  int first_status = FLATE_HIP_OK;
+  for (uint32_t g = 0; g < G; ++g) {
+    if (!pipe.wait_in(g)) {
+      rc = FLATE_HIP_E_HIP;
+      break;
+    }
+    const uint32_t a = lo[g], cnt = lo[g + 1] - lo[g];
+    gin.resize((size_t)cnt + 1);
+    gout.resize((size_t)cnt + 1);
+    for (uint32_t i = 0; i <= cnt; ++i) {
+      gin[i] = in_off[a + i] - in_off[a];
+      gout[i] = out_off[a + i] - out_off[a];
+    }
+    if (cnt) {
+      const int r = inflate_common(c, d_in + in_off[a], gin.data(), cnt, d_out + out_off[a], gout.data(),
+                                   out_len + a, status + a, err_off + a, flags | FLATE_HIP_DEVICE_PTRS, 0);
+      // a stream's own failure (its status, also the return value) does not stop the batch: as in
+      // one pass, every stream is decoded and the first failing status is what the call returns
+      const bool stream_status = r == FLATE_HIP_E_CORRUPT || r == FLATE_HIP_E_UNEXPECTED_EOF ||
+                                 r == FLATE_HIP_E_OUT_TOO_SMALL;
+      if (r != FLATE_HIP_OK && !stream_status) {
+        rc = r;
+        break;
+      }
+      if (first_status == FLATE_HIP_OK) first_status = r;
+      for (int k = 0; k < FLATE_HIP_STAGE_COUNT; ++k) stage_sum[k] += c->stage_ms[k];
+    }
+    pipe.post_out(g, {out + out_off[a], d_out + out_off[a], (size_t)gout[cnt]});
+  }
+  const std::string err = pipe.finish();
+  if (rc == FLATE_HIP_OK) rc = first_status;
+  if ((rc == FLATE_HIP_OK || rc == first_status) && !err.empty()) rc = FLATE_HIP_E_HIP;
+  if (rc == FLATE_HIP_E_HIP && c->hip_err.empty()) c->hip_err = err;
+  for (int k = 0; k < FLATE_HIP_STAGE_COUNT; ++k) c->stage_ms[k] = stage_sum[k];
+  return rc;
+}
+
 extern "C" {
 
 int flate_hip_inflate_batch(flate_hip_ctx *c, const uint8_t *in, const uint64_t *in_off, uint32_t n,
@@ -1031,6 +1106,13 @@ int flate_hip_inflate_batch(flate_hip_ctx *c, const uint8_t *in, const uint64_t 
     if (in_off[i + 1] < in_off[i] || out_off[i + 1] < out_off[i]) return FLATE_HIP_E_INVALID;
   for (uint32_t i = 0; i < n; ++i)
     if (in_off[i + 1] - in_off[i] >= 0x7ffe0000ull) return FLATE_HIP_E_TOO_LARGE;
+  // host pointers and a large batch: decode group g while g+1 is copied in and g-1 out
+  if (!(flags & FLATE_HIP_DEVICE_PTRS) && c->host_groups > 1 &&
+      in_off[n] - in_off[0] + out_off[n] - out_off[0] >= (64ull << 20)) {
+    uint32_t G = (uint32_t)c->host_groups;
+    if (n / 16384u < G) G = n / 16384u;  // (a group should still fill the lane-per-stream launch)
+    if (G > 1) return inflate_host_pipelined(c, in, in_off, n, out, out_off, out_len, status, err_off, flags, G);
+  }
   return inflate_common(c, in, in_off, n, out, out_off, out_len, status, err_off, flags, 0);
 }
 

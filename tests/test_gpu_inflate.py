@@ -144,3 +144,42 @@ def test_inflate_fuzz_foreign_block_mixes(eng, oracle):
     assert (status == 0).all() and list(olen) == sizes
     for i, p in enumerate(plains):
         assert bytes(out[int(ooff[i]):int(ooff[i]) + len(p)]) == p, i
+
+
+def test_host_pointer_pipeline_matches_single_pass(oracle):
+    # host-pointer calls on large batches are pipelined over groups of streams (option
+    # host_pipeline_groups): outputs, lengths, statuses and error offsets equal those of one pass,
+    # also when streams of different groups are corrupt or cut short
+    n, blen = 49152 + 11, 2048
+    host = flate.synth("text", n, blen)
+    off = flate.uniform_offsets(n, blen)
+    e = flate.FlateEngine(0)
+    try:
+        comp, coff = e.deflate_batch(host, off)
+        comp = np.array(np.asarray(comp)[:int(coff[-1]) + 8], copy=True)
+        bad = [5, 20000, 40000, n - 1]
+        for k, i in enumerate(bad):  # corrupt block type / damaged code data
+            a, b = int(coff[i]), int(coff[i + 1])
+            if k % 2 == 0:
+                comp[a] |= 0x06
+            else:
+                comp[a + (b - a) // 2: b] = 0xff
+        sizes = [blen] * n
+        e.set_option("host_pipeline_groups", 0)
+        ref = e.inflate_batch(comp, coff, sizes, check=False)
+        e.set_option("host_pipeline_groups", 3)
+        got = e.inflate_batch(comp, coff, sizes, check=False)
+        assert (ref[3] != 0).sum() >= 2 and (ref[3][[i for i in range(n) if i not in bad]] == 0).all()
+        for r, g in zip(ref[1:], got[1:]):  # out_off, out_len, status, err_off
+            assert np.array_equal(np.asarray(r), np.asarray(g))
+        ok = np.asarray(ref[3]) == 0
+        o_ref = np.asarray(ref[0])[:n * blen].reshape(n, blen)
+        o_got = np.asarray(got[0])[:n * blen].reshape(n, blen)
+        assert np.array_equal(o_ref[ok], o_got[ok])
+        assert np.array_equal(o_got[ok], np.asarray(host)[:n * blen].reshape(n, blen)[ok])
+        for i in bad:  # and the oracle's decoder agrees on the failing streams
+            rc, _, _, eoff = oracle.inflate(bytes(comp[int(coff[i]):int(coff[i + 1])]), blen, full=True)
+            want = {0: 0, oracle.E_CORRUPT: -4, oracle.E_UNEXPECTED_EOF: -7, oracle.E_OUT_TOO_SMALL: -2}[rc]
+            assert want == int(got[3][i]) and eoff == int(got[4][i]), (i, rc, eoff, int(got[3][i]), int(got[4][i]))
+    finally:
+        e.close()
