@@ -63,13 +63,13 @@ int flate_hip_set_stream(flate_hip_ctx *ctx, void *hip_stream);
  *   "guest_blocks"       extra persistent wavefronts whose hash table lives in L2 instead of LDS
  *                        (default 6.5 per CU; 0 = off)
  *   "resident_blocks"    persistent LDS-table wavefronts (default 4 per CU)
- *   "guest_min_streams"  batches smaller than this use one block per stream (default 4096)
+ *   "guest_min_streams"  batches smaller than this use one block per stream (default 5 per CU = 1280)
  *   "window_units"       1 (default): multi-window streams of a persistent launch are scheduled one
  *                        65535-byte window at a time (a stream's table rests in global memory
  *                        between its windows); 0: one block keeps a stream from start to end
  *   "host_pipeline_groups"  host-pointer calls of flate_hip_deflate_fast_batch / flate_hip_inflate_batch
  *                        on >= 64 MiB: the batch is cut into this many groups of streams (each at
- *                        least guest_min_streams, for inflate 16384) and
+ *                        least 4096 streams, for inflate 16384) and
  *                        group g is compressed while group g+1 is copied in and the output of g-1
  *                        is copied out (default 4; 0 or 1: copy in, compress, copy out)
  *   "overlap_sub_batches"  > 0: the entropy kernels of every sub-batch (queue order) run on a
