@@ -208,7 +208,7 @@ def test_full_size_config3_multi_window(eng, oracle):
 
 
 def test_full_size_config3_default_geometry(oracle):
-    # BASELINE configs[2] at FULL size with the DEFAULT launch geometry: 4096 x 256 KiB streams is at
+    # BASELINE configs[2] at FULL size with the DEFAULT launch geometry: 4096 x 256 KiB streams is above
     # guest_min_streams, so the persistent resident + guest MULTI kernels (shared queue, swept 16-bit
     # tables) are what runs.  Both compat modes; byte-exact against the oracle on a strided sample,
     # and every stream round-trips through the GPU inflater.
