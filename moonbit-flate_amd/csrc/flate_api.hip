@@ -562,7 +562,7 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
   if ((rc = ensure(c, c->d_blk_cl, nb * 320 * 4))) return rc;
   if ((rc = ensure(c, c->d_blk_hdr, nb * 704 * 4))) return rc;
   if ((rc = ensure(c, c->d_blk_meta, nb * 16))) return rc;
-  if ((rc = ensure(c, c->d_tile_meta, nb * 16384))) return rc;  // 256 tiles x 64 lanes per block
+  if ((rc = ensure(c, c->d_tile_meta, ((in_bytes >> 8) + nb + 2) * 64))) return rc;  // (tile_meta_at)
   if ((rc = ensure(c, c->d_out_len, (size_t)n * 8 + 8))) return rc;
   if ((rc = ensure(c, c->d_out_off, ((size_t)n + 1) * 8))) return rc;
   if (spliced) {

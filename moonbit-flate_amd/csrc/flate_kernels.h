@@ -57,7 +57,7 @@ struct HuffParams {
   uint32_t *blk_hist;  // per block 320 u32: literal/length histogram [0,286), offsets [288,318)
   uint32_t *blk_cl;    // per block 320 u32: (len << 16) | bit-reversed code, same layout
   uint32_t *blk_hdr;   // per block 704 u32: dynamic-header items (nbits << 16) | value
-  uint8_t *tile_meta;  // per block 16 KiB: one byte per lane and 256-position tile, written by
+  uint8_t *tile_meta;  // input / 4 bytes: one byte per lane and 256-position tile, written by
                        // huff_hist_kernel and read by huff_pack_kernel (see TileTok::pack)
   uint4 *blk_meta;     // per block {kind 0 stored / 1 huffman-only / 2 dynamic, header items, start bit lo, hi}
   // spliced mode (one DEFLATE stream for the whole batch, splice_kernels.hip); 0/NULL otherwise

@@ -390,7 +390,12 @@ struct TileTok {
   // all precede its match.
   FLATE_D uint32_t pack() const { return lit_mask | (match_k >= 0 ? 0x10u | ((uint32_t)match_k << 5) : 0u); }
 };
-constexpr int kTileMetaPerBlock = 16384;  // 256 tiles (65535 positions) x 64 lanes
+// Where a block's tile rows (64 bytes per 256-position tile) start in HuffParams::tile_meta: by
+// the block's position in the input plus its index, so that the whole array is input / 4 bytes
+// plus one row per block (a block of n bytes has ceil(n / 256) <= n / 256 + 1 rows).
+FLATE_D uint64_t tile_meta_at(uint64_t block_start_in_input, uint32_t gb) {
+  return ((block_start_in_input >> 8) + gb) * 64u;
+}
 
 struct Walker {
   const uint8_t *src;
@@ -671,7 +676,7 @@ __global__ __launch_bounds__(64) void huff_hist_kernel(HuffParams P) {
       const uint32_t chunk = g.chunk0 + b;
       Walker w = walker_init(src, P.matches + (uint64_t)chunk * kMatchCapPerChunk, P.chunk_nmatch[chunk],
                              n, lane);
-      uint8_t *tmeta = P.tile_meta + (uint64_t)gb * kTileMetaPerBlock;
+      uint8_t *tmeta = P.tile_meta + tile_meta_at((uint64_t)(src - P.in), gb);
       for (int P0 = 0; P0 < n; P0 += kTile) {
         const TileTok t = walk_tile(sh, w, P0, lane);
         tmeta[(P0 >> 2) + lane] = (uint8_t)t.pack();
@@ -893,7 +898,7 @@ __global__ __launch_bounds__(64) void huff_pack_kernel(HuffParams P) {
       // Everything a tile needs is loaded one tile ahead (its meta byte two ahead).
       const uint32_t chunk = g.chunk0 + b;
       const uint2 *recs = P.matches + (uint64_t)chunk * kMatchCapPerChunk;
-      const uint8_t *tmeta = P.tile_meta + (uint64_t)gb * kTileMetaPerBlock;
+      const uint8_t *tmeta = P.tile_meta + tile_meta_at((uint64_t)(src - P.in), gb);
       Walker w = walker_init(src, nullptr, 0u, n, lane);  // (input bytes only)
       const int ntiles = (n + kTile - 1) / kTile;
       uint32_t mp = 0;
