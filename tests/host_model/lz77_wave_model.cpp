@@ -21,6 +21,8 @@ inline uint32_t ld32(const uint8_t *p) {
   return v;
 }
 inline uint32_t hash4(uint32_t u) { return (u * 0x1e35a7bdu) >> 18; }
+// the guest blocks' 2-bit slot tag (lz77_kernels.hip, tag_of): the two product bits below the slot index
+inline uint32_t tag_of(uint32_t u) { return ((u * 0x1e35a7bdu) >> 16) & 3u; }
 inline int ctz64(uint64_t m) { return m ? __builtin_ctzll(m) : 64; }
 inline uint64_t below(int l) { return l >= 64 ? ~0ull : ((1ull << l) - 1); }  // lanes < l
 inline uint64_t upto(int l) { return l >= 63 ? ~0ull : ((1ull << (l + 1)) - 1); }  // lanes <= l
@@ -47,9 +49,14 @@ struct Stats { uint64_t dense_batches, sparse_batches, events, dup_evals, discar
 
 }  // namespace
 
-extern "C" int model_lz77(const uint8_t *stream, uint64_t len, int compat_go, uint32_t *recs_out,
+// flags: bit 0 = compat_go; bit 1 = model the guest blocks' slot tags (a dense-batch lane whose own
+// tag differs from its slot's skips the slot read: its candidate could not pass `cv == cand.val`)
+extern "C" int model_lz77(const uint8_t *stream, uint64_t len, int flags, uint32_t *recs_out,
                           uint32_t *chunk_nmatch, uint64_t *stats_out) {
+  const int compat_go = flags & 1;
+  const bool use_tags = (flags & 2) != 0;
   std::vector<uint32_t> table(kTableSize, 0);
+  std::vector<uint8_t> tags(kTableSize, 0);
   std::vector<uint32_t> scantab;
   {
     uint32_t skip = 32, pos = 0;
@@ -108,7 +115,7 @@ extern "C" int model_lz77(const uint8_t *stream, uint64_t len, int compat_go, ui
           memcpy(own[L], src + q[L], 16);
           cv[L] = ld32(src + q[L]);
           h[L] = hash4(cv[L]);
-          old[L] = table[h[L]];
+          old[L] = (use_tags && tags[h[L]] != tag_of(cv[L])) ? 0u : table[h[L]];
           if (old[L] != 0 && A1[L] - old[L] <= 32768u) {
             mlen[L] = common_prefix16(own[L], stream + (old[L] - 1));
             if (mlen[L] >= 4) OK |= 1ull << L;
@@ -206,7 +213,10 @@ extern "C" int model_lz77(const uint8_t *stream, uint64_t len, int compat_go, ui
         }
         // commit the inserts in position order (later positions overwrite earlier ones)
         for (int L = 0; L < 64; ++L)
-          if ((INS >> L) & 1) table[h[L]] = A1[L];
+          if ((INS >> L) & 1) {
+            table[h[L]] = A1[L];
+            tags[h[L]] = (uint8_t)tag_of(cv[L]);
+          }
       } else {
         // ----------------------------- sparse batch -------------------------------
         st.sparse_batches++;
@@ -224,6 +234,7 @@ extern "C" int model_lz77(const uint8_t *stream, uint64_t len, int compat_go, ui
           const uint32_t cvL = ld32(src + p[L]), hL = hash4(cvL), A1L = W + (uint32_t)p[L] + 1;
           const uint32_t o = table[hL];
           table[hL] = A1L;
+          tags[hL] = (uint8_t)tag_of(cvL);
           if (o != 0 && A1L - o <= 32768u && ld32(stream + (o - 1)) == cvL) { f = L; cand = o - 1; break; }
         }
         if (f == 64) {

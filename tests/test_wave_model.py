@@ -24,14 +24,14 @@ def model():
     return L
 
 
-def run_model(model, sb, compat_go=False):
+def run_model(model, sb, compat_go=False, slot_tags=False):
     sb = np.ascontiguousarray(sb, dtype=np.uint8)
     nch = len(flate.lz_chunks(sb.size))
     recs = np.zeros((max(nch, 1) * 16384, 2), dtype=np.uint32)
     nm = np.zeros(max(nch, 1), dtype=np.uint32)
     stats = np.zeros(8, dtype=np.uint64)
     pad = np.concatenate([sb, np.zeros(64, np.uint8)])  # the model may read own16 near the end
-    got = model.model_lz77(pad.ctypes.data, sb.size, 1 if compat_go else 0, recs.ctypes.data,
+    got = model.model_lz77(pad.ctypes.data, sb.size, (1 if compat_go else 0) | (2 if slot_tags else 0), recs.ctypes.data,
                            nm.ctypes.data, stats.ctypes.data)
     assert got == nch
     out = []
@@ -41,12 +41,12 @@ def run_model(model, sb, compat_go=False):
     return out, stats
 
 
-def check(model, oracle, specs, compat_go=False, seed=1234):
+def check(model, oracle, specs, compat_go=False, seed=1234, slot_tags=False):
     data, off = make_streams(specs, seed=seed)
     tot = np.zeros(8, dtype=np.uint64)
     for i, (kind, n) in enumerate(specs):
         sb = data[int(off[i]):int(off[i + 1])]
-        chunks, stats = run_model(model, sb, compat_go)
+        chunks, stats = run_model(model, sb, compat_go, slot_tags)
         tot += stats
         want = oracle_tokens_per_chunk(oracle, sb, compat=1 if compat_go else 0)
         for k, ((start, cn), w) in enumerate(zip(flate.lz_chunks(n), want)):
@@ -86,3 +86,14 @@ def test_model_batches_amortise_events(model, oracle):
     st = check(model, oracle, [("text", 65536)] * 4)
     dense, sparse, events = int(st[0]), int(st[1]), int(st[2])
     assert events / (dense + sparse) > 3.0, (dense, sparse, events)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_model_slot_tags_change_nothing(model, oracle, seed):
+    # the guest blocks' 2-bit slot tags (lz77_kernels.hip: tag_of / tag_set) only skip slot reads
+    # that could not have produced a match: same tokens as the oracle with the filter on
+    rng = np.random.default_rng(100 + seed)
+    specs = [(KINDS[int(rng.integers(0, len(KINDS)))], int(rng.integers(128, 140000))) for _ in range(20)]
+    specs += [(k, 65536) for k in KINDS]
+    check(model, oracle, specs, seed=seed, slot_tags=True)
+    check(model, oracle, specs[:8], compat_go=True, seed=seed, slot_tags=True)
