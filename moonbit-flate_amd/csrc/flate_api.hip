@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <condition_variable>
+#include <exception>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -738,8 +739,11 @@ struct CopyJob {
 };
 class CopyPipe {
  public:
-  CopyPipe(int device, hipStream_t s_in, hipStream_t s_out, std::vector<CopyJob> in_jobs, size_t n_out)
-      : in_ready_(in_jobs.size(), 0), out_state_(n_out, 0), out_jobs_(n_out) {
+  CopyPipe(size_t n_in, size_t n_out) : in_ready_(n_in, 0), out_state_(n_out, 0), out_jobs_(n_out) {}
+  // (not in the constructor: if the second thread cannot be created, the destructor must still run
+  // to join the first)
+  void start(int device, hipStream_t s_in, hipStream_t s_out, std::vector<CopyJob> in_jobs) {
+    const size_t n_out = out_jobs_.size();
     t_in_ = std::thread([this, device, s_in, in_jobs] {
       (void)hipSetDevice(device);
       for (size_t g = 0; g < in_jobs.size(); ++g) {
@@ -836,7 +840,8 @@ static int deflate_host_pipelined(flate_hip_ctx *c, const uint8_t *in, const uin
   for (uint32_t g = 0; g <= G; ++g) lo[g] = (uint32_t)((uint64_t)n * g / G);
   for (uint32_t g = 0; g < G; ++g)
     in_jobs[g] = {d_in + in_off[lo[g]], in + in_off[lo[g]], (size_t)(in_off[lo[g + 1]] - in_off[lo[g]])};
-  CopyPipe pipe(c->device, c->h2d_stream, c->d2h_stream, in_jobs, G);
+  CopyPipe pipe(G, G);
+  pipe.start(c->device, c->h2d_stream, c->d2h_stream, in_jobs);
 
   float stage_sum[FLATE_HIP_STAGE_COUNT] = {0, 0, 0, 0};
   std::vector<uint64_t> goff, gin;
@@ -890,7 +895,11 @@ int flate_hip_deflate_fast_batch(flate_hip_ctx *c, const uint8_t *in, const uint
       StagePlan pl;  // validate the whole index first (the same checks as the one-call path)
       const int rc = make_plan(in_off, n, pl);
       if (rc) return rc;
-      return deflate_host_pipelined(c, in, in_off, n, out, out_cap, out_off, flags, G);
+      try {
+        return deflate_host_pipelined(c, in, in_off, n, out, out_cap, out_off, flags, G);
+      } catch (const std::exception &e) {  // (no copy threads, out of host memory): one pass instead
+        c->hip_err.clear();
+      }
     }
   }
   return deflate_common(c, in, in_off, n, out, out_cap, out_off, flags, false, nullptr);
@@ -1054,7 +1063,8 @@ static int inflate_host_pipelined(flate_hip_ctx *c, const uint8_t *in, const uin
   for (uint32_t g = 0; g <= G; ++g) lo[g] = (uint32_t)((uint64_t)n * g / G);
   for (uint32_t g = 0; g < G; ++g)
     in_jobs[g] = {d_in + in_off[lo[g]], in + in_off[lo[g]], (size_t)(in_off[lo[g + 1]] - in_off[lo[g]])};
-  CopyPipe pipe(c->device, c->h2d_stream, c->d2h_stream, in_jobs, G);
+  CopyPipe pipe(G, G);
+  pipe.start(c->device, c->h2d_stream, c->d2h_stream, in_jobs);
   float stage_sum[FLATE_HIP_STAGE_COUNT] = {0, 0, 0, 0};
   std::vector<uint64_t> gin, gout;
   rc = FLATE_HIP_OK;
@@ -1113,7 +1123,13 @@ int flate_hip_inflate_batch(flate_hip_ctx *c, const uint8_t *in, const uint64_t 
       in_off[n] - in_off[0] + out_off[n] - out_off[0] >= (64ull << 20)) {
     uint32_t G = (uint32_t)c->host_groups;
     if (n / 16384u < G) G = n / 16384u;  // (a group should still fill the lane-per-stream launch)
-    if (G > 1) return inflate_host_pipelined(c, in, in_off, n, out, out_off, out_len, status, err_off, flags, G);
+    if (G > 1) {
+      try {
+        return inflate_host_pipelined(c, in, in_off, n, out, out_off, out_len, status, err_off, flags, G);
+      } catch (const std::exception &e) {  // (no copy threads, out of host memory): one pass instead
+        c->hip_err.clear();
+      }
+    }
   }
   return inflate_common(c, in, in_off, n, out, out_off, out_len, status, err_off, flags, 0);
 }
