@@ -59,7 +59,9 @@ struct Shared {
   uint32_t first_code[17];
   uint32_t len_base[17];
   // header
-  uint8_t codegen[320];
+  uint8_t codegen[320];    // the codegen symbols (0..18), one per item
+  uint8_t cg_extra[320];   // the repeat count carried by a 16 / 17 / 18 item
+  uint32_t cg_n;           // number of items
   uint16_t hdr_val[kHdrMax];
   uint8_t hdr_nb[kHdrMax];
   uint32_t hdr_n;
@@ -501,96 +503,147 @@ FLATE_D void emit_stored(BitSink &S, const uint8_t *src, int n, bool eof, int la
 
 // generate_codegen (:241-330) + codegen code + dynamic_size (:335-360) + header items.
 // Returns size in bits (for the stored decision) and leaves the header in hdr_*.
+// Wave-parallel: the reference's loops over the ~300 code lengths are (1) runs of equal lengths
+// found with ballots, (2) per run the closed form of the greedy loops of :262-327 -- a non-zero
+// length v repeated c times is v, then (c-1)/6 times "16, 3", then "16, rem-3" if the remainder
+// is >= 3 or the remainder as plain v's; a zero run is c/138 times "18, 127", then "18, rem-11"
+// if rem >= 11, else "17, rem-3" if rem >= 3, else rem plain zeros -- written at the offset a
+// prefix sum over the runs gives, (3) after the codegen code is built, one header entry per item
+// plus one per repeat count, again placed by a prefix sum.  (A lane-0 loop with two dependent LDS
+// reads per element cost about half of huff_code_kernel's time.)
 FLATE_D uint32_t make_header(Shared &sh, int num_literals, int num_offsets, int lane) {
+  const int total = num_literals + num_offsets;  // <= 316
+  auto len_at = [&](int i) -> uint32_t {
+    return i < num_literals ? (sh.lit_cl[i] >> 16) : (sh.off_cl[i - num_literals] >> 16);
+  };
   if (lane < 20) sh.cg_freq[lane] = 0;
-  __syncthreads();
-  if (lane == 0) {
-    // run-length code the concatenated code lengths
-    const int total = num_literals + num_offsets;
-    int out = 0;
-    int i = 0;
-    while (i < total) {
-      const uint32_t v = i < num_literals ? (sh.lit_cl[i] >> 16) : (sh.off_cl[i - num_literals] >> 16);
-      int j = i + 1;
-      while (j < total) {
-        const uint32_t u = j < num_literals ? (sh.lit_cl[j] >> 16) : (sh.off_cl[j - num_literals] >> 16);
-        if (u != v) break;
-        ++j;
-      }
-      int count = j - i;
-      if (v != 0) {
-        sh.codegen[out++] = (uint8_t)v;
-        sh.cg_freq[v]++;
-        count--;
-        while (count >= 3) {
-          const int r = count < 6 ? count : 6;
-          sh.codegen[out++] = 16;
-          sh.codegen[out++] = (uint8_t)(r - 3);
-          sh.cg_freq[16]++;
-          count -= r;
-        }
-      } else {
-        while (count >= 11) {
-          const int r = count < 138 ? count : 138;
-          sh.codegen[out++] = 18;
-          sh.codegen[out++] = (uint8_t)(r - 11);
-          sh.cg_freq[18]++;
-          count -= r;
-        }
-        if (count >= 3) {
-          sh.codegen[out++] = 17;
-          sh.codegen[out++] = (uint8_t)(count - 3);
-          sh.cg_freq[17]++;
-          count = 0;
-        }
-      }
-      for (; count > 0; --count) {
-        sh.codegen[out++] = (uint8_t)v;
-        sh.cg_freq[v]++;
-      }
-      i = j;
-    }
-    sh.codegen[out] = 0xff;  // bad_code terminator (:329)
+  // (1) run starts, in order (+ the end).  The list lives in the package-merge scratch, which is
+  // idle between two code constructions (one more KiB of LDS would cost a wavefront per CU).
+  uint16_t *run_pos = reinterpret_cast<uint16_t *>(&sh.lv[0][0]);
+  uint32_t nruns = 0;
+  for (int t = 0; t < 5; ++t) {
+    const int i = t * 64 + lane;
+    const bool start = i < total && (i == 0 || len_at(i) != len_at(i - 1));
+    const uint64_t m = __ballot(start);
+    if (start) run_pos[nruns + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
+    nruns += (uint32_t)__popcll(m);
   }
+  if (lane == 0) run_pos[nruns] = (uint16_t)total;
+  __syncthreads();
+  // (2) the items of every run
+  uint32_t nitems = 0;
+  for (uint32_t r0 = 0; r0 < nruns; r0 += 64) {
+    const uint32_t r = r0 + (uint32_t)lane;
+    uint32_t v = 0, c = 0, k_big = 0, tail_sym = 0, tail_extra = 0, plain = 0;
+    bool has_tail = false;
+    if (r < nruns) {
+      const int p = run_pos[r];
+      c = (uint32_t)run_pos[r + 1] - (uint32_t)p;
+      v = len_at(p);
+      if (v != 0) {
+        const uint32_t rem = c - 1u;
+        k_big = rem / 6u;  // "16, 3" (repeat 6)
+        const uint32_t lo = rem - 6u * k_big;
+        has_tail = lo >= 3u;
+        tail_sym = 16u;
+        tail_extra = lo - 3u;
+        plain = 1u + (has_tail ? 0u : lo);
+      } else {
+        k_big = c / 138u;  // "18, 127" (repeat 138)
+        uint32_t lo = c - 138u * k_big;
+        if (lo >= 11u) {
+          has_tail = true;
+          tail_sym = 18u;
+          tail_extra = lo - 11u;
+          lo = 0;
+        } else if (lo >= 3u) {
+          has_tail = true;
+          tail_sym = 17u;
+          tail_extra = lo - 3u;
+          lo = 0;
+        }
+        plain = lo;
+      }
+    }
+    const uint32_t mine = r < nruns ? plain + k_big + (has_tail ? 1u : 0u) : 0u;
+    const uint32_t incl = wave_incl_scan(mine);
+    uint32_t at = nitems + incl - mine;
+    nitems += rdlane(incl, 63);
+    if (r < nruns) {
+      const uint32_t big_sym = v != 0 ? 16u : 18u, big_extra = v != 0 ? 3u : 127u;
+      if (v != 0) {  // the first occurrence is always written plainly (:276-279)
+        sh.codegen[at] = (uint8_t)v;
+        sh.cg_extra[at++] = 0;
+      }
+      for (uint32_t k = 0; k < k_big; ++k) {
+        sh.codegen[at] = (uint8_t)big_sym;
+        sh.cg_extra[at++] = (uint8_t)big_extra;
+      }
+      if (has_tail) {
+        sh.codegen[at] = (uint8_t)tail_sym;
+        sh.cg_extra[at++] = (uint8_t)tail_extra;
+      }
+      for (uint32_t k = v != 0 ? 1u : 0u; k < plain; ++k) {
+        sh.codegen[at] = (uint8_t)v;
+        sh.cg_extra[at++] = 0;
+      }
+      if (plain) atomicAdd(&sh.cg_freq[v], plain);
+      const uint32_t n_big = k_big + ((has_tail && tail_sym == big_sym) ? 1u : 0u);
+      if (n_big) atomicAdd(&sh.cg_freq[big_sym], n_big);
+      if (has_tail && tail_sym == 17u) atomicAdd(&sh.cg_freq[17], 1u);
+    }
+  }
+  if (lane == 0) sh.cg_n = nitems;
   __syncthreads();
   build_code(sh, sh.cg_freq, kCodegenCodeCount, 7, sh.cg_cl, lane);
 
-  uint32_t size = 0;
+  // (3) header entries: HLIT, HDIST, HCLEN, the code lengths of the codegen code in codegen_order
+  // (trailing zeros dropped, at least four), then the items (:421-471)
+  const bool in_order = lane < kCodegenCodeCount;
+  const uint32_t ord_freq = in_order ? sh.cg_freq[kCodegenOrder[lane]] : 0u;
+  const uint64_t nz = __ballot(ord_freq != 0);
+  int ncg = nz ? 64 - (int)__builtin_clzll(nz) : 0;
+  if (ncg < 4) ncg = 4;
+  uint32_t term = 0;
+  if (in_order) {
+    const uint32_t f = sh.cg_freq[lane];
+    term = f * (sh.cg_cl[lane] >> 16) + (lane == 16 ? 2u * f : (lane == 17 ? 3u * f : (lane == 18 ? 7u * f : 0u)));
+  }
+  const uint32_t size = 3u + 5u + 5u + 4u + 3u * (uint32_t)ncg + wave_sum(term);
   if (lane == 0) {
-    const uint8_t *order = kCodegenOrder;
-    int ncg = kCodegenCodeCount;
-    while (ncg > 4 && sh.cg_freq[order[ncg - 1]] == 0) ncg--;
-    uint32_t header = 3 + 5 + 5 + 4 + 3 * (uint32_t)ncg + sh.cg_freq[16] * 2 +
-                      sh.cg_freq[17] * 3 + sh.cg_freq[18] * 7;
-    for (int k = 0; k < kCodegenCodeCount; ++k) header += sh.cg_freq[k] * (sh.cg_cl[k] >> 16);
-    size = header;
-    int h = 0;
-    sh.hdr_val[h] = 4;  // BFINAL=0, BTYPE=10 (callers never pass eof, deflate.mbt:251,267,269)
-    sh.hdr_nb[h++] = 3;
-    sh.hdr_val[h] = (uint32_t)(num_literals - 257);
-    sh.hdr_nb[h++] = 5;
-    sh.hdr_val[h] = (uint32_t)(num_offsets - 1);
-    sh.hdr_nb[h++] = 5;
-    sh.hdr_val[h] = (uint32_t)(ncg - 4);
-    sh.hdr_nb[h++] = 4;
-    for (int k = 0; k < ncg; ++k) {
-      sh.hdr_val[h] = sh.cg_cl[order[k]] >> 16;
-      sh.hdr_nb[h++] = 3;
-    }
-    for (int k = 0;; ++k) {
-      const uint32_t cw = sh.codegen[k];
-      if (cw == 0xff) break;
+    sh.hdr_val[0] = 4;  // BFINAL=0, BTYPE=10 (callers never pass eof, deflate.mbt:251,267,269)
+    sh.hdr_nb[0] = 3;
+    sh.hdr_val[1] = (uint16_t)(num_literals - 257);
+    sh.hdr_nb[1] = 5;
+    sh.hdr_val[2] = (uint16_t)(num_offsets - 1);
+    sh.hdr_nb[2] = 5;
+    sh.hdr_val[3] = (uint16_t)(ncg - 4);
+    sh.hdr_nb[3] = 4;
+  }
+  if (lane < ncg) {
+    sh.hdr_val[4 + lane] = (uint16_t)(sh.cg_cl[kCodegenOrder[lane]] >> 16);
+    sh.hdr_nb[4 + lane] = 3;
+  }
+  uint32_t h = 4u + (uint32_t)ncg;
+  for (uint32_t k0 = 0; k0 < nitems; k0 += 64) {
+    const uint32_t k = k0 + (uint32_t)lane;
+    const bool live = k < nitems;
+    const uint32_t cw = live ? sh.codegen[k] : 0u;
+    const uint32_t ents = live ? (cw >= 16u ? 2u : 1u) : 0u;
+    const uint32_t incl = wave_incl_scan(ents);
+    const uint32_t at = h + incl - ents;
+    h += rdlane(incl, 63);
+    if (live) {
       const uint32_t c = sh.cg_cl[cw];
-      sh.hdr_val[h] = c & 0xffffu;
-      sh.hdr_nb[h++] = (uint8_t)(c >> 16);
-      if (cw >= 16) {
-        sh.hdr_val[h] = sh.codegen[++k];
-        sh.hdr_nb[h++] = cw == 16 ? 2 : (cw == 17 ? 3 : 7);
+      sh.hdr_val[at] = (uint16_t)(c & 0xffffu);
+      sh.hdr_nb[at] = (uint8_t)(c >> 16);
+      if (cw >= 16u) {
+        sh.hdr_val[at + 1] = sh.cg_extra[k];
+        sh.hdr_nb[at + 1] = cw == 16u ? 2 : (cw == 17u ? 3 : 7);
       }
     }
-    sh.hdr_n = (uint32_t)h;
   }
-  size = rdlane(size, 0);
+  if (lane == 0) sh.hdr_n = h;
   __syncthreads();
   return size;
 }
