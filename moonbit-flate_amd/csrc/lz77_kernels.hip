@@ -167,6 +167,23 @@ __global__ __launch_bounds__(64) void lz77_serial_kernel(LzParams P) {
 // skips both the table gather and the candidate gather: the guest tables live in the Infinity
 // Cache (profiles/r02/lz77_traffic.json) and those gathers are what fills the vector L1's miss
 // queue.  Exact: every table write also writes the tag.
+// The lanes of `among` whose slot h equals mine: one ballot per hash bit.  Per bit and half of the
+// mask, `eq &= ~(m ^ bm)` with bm = 0 / -1 from my own bit is one three-input VALU operation
+// (v_bitop3_b32), 4 VALU per bit; written with `bit ? m : ~m` on the 64-bit mask the compiler
+// spent 9 (SQ counters: 331 VALU per guest batch against 200 per LDS-table batch).
+FLATE_D uint64_t same_slot_lanes(uint32_t h, uint64_t among) {
+  uint32_t lo = (uint32_t)among, hi = (uint32_t)(among >> 32);
+#pragma unroll
+  for (int k = 0; k < kTableBits; ++k) {
+    uint32_t bm = (uint32_t)((int32_t)(h << (31 - k)) >> 31);  // my bit k, as 0 / ~0 (v_bfe_i32)
+    asm volatile("" : "+v"(bm));  // (or the compare is derived from h again: one more shift per bit)
+    const uint64_t m = __ballot(bm != 0);
+    lo &= ~((uint32_t)m ^ bm);
+    hi &= ~((uint32_t)(m >> 32) ^ bm);
+  }
+  return ((uint64_t)hi << 32) | lo;
+}
+
 FLATE_D uint32_t tag_of(uint32_t cv) { return ((cv * 0x1e35a7bdu) >> 16) & 3u; }
 FLATE_D uint32_t tag_get(const uint32_t *tags, uint32_t h) { return (tags[h >> 4] >> (2u * (h & 15u))) & 3u; }
 FLATE_D void tag_set(uint32_t *tags, uint32_t h, uint32_t t) {
@@ -280,13 +297,7 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
           // With the table in L2 a speculative insert + read-back costs two more memory round
           // trips per batch; the lanes with equal hashes are found with one ballot per hash bit
           // instead and the table is not touched before the commit.
-          eq = E1;
-#pragma unroll
-          for (int k = 0; k < kTableBits; ++k) {
-            const bool bit = (h >> k) & 1u;
-            const uint64_t m = __ballot(bit);
-            eq &= bit ? m : ~m;
-          }
+          eq = same_slot_lanes(h, E1);
           if (!e1) eq = 0;
           DUPall = __ballot((eq & ~(1ull << lane)) != 0);
           DUP = __ballot((eq & lanes_below(lane)) != 0);
@@ -594,13 +605,7 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
         const bool ins = lane <= lim;
         uint64_t C;
         if (GUEST) {  // same-slot lanes among the inserted ones by ballots (see the dense batch)
-          uint64_t eqs = __ballot(ins);
-#pragma unroll
-          for (int k = 0; k < kTableBits; ++k) {
-            const bool bit = (h >> k) & 1u;
-            const uint64_t m = __ballot(bit);
-            eqs &= bit ? m : ~m;
-          }
+          const uint64_t eqs = same_slot_lanes(h, __ballot(ins));
           C = __ballot(ins && (eqs & ~(1ull << lane)) != 0);
           if (C == 0 && ins) {
             vtable[h] = (E)A1;
