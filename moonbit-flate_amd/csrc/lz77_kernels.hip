@@ -250,6 +250,10 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
     uint64_t st_load = 0, st_dup = 0, st_ev = 0, st_commit = 0, st_sparse = 0, st_nb = 0, st_ext = 0;
 #endif
 
+    // the probe lanes of an event starting at my lane when every lane of the batch is inside the chunk
+    const uint64_t spec_full =
+        (2ull << lane) | (lane + 2 < 64 ? ((0x00000000ffffffffull << (lane + 2)) | (0x5555555500000000ull << (lane + 2)))
+                                        : 0ull);
     while (!done) {
       if (!sparse) {
         // =============================== dense batch ===============================
@@ -330,10 +334,14 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
         // probe lanes of the event that would start with s-1 == my lane (independent of the
         // candidate bytes still in flight)
         const int bsh = lane + 2;  // (lanes 62, 63 have no scan lanes left: shift counts stay < 64)
-        const uint64_t specR = (E1 & (2ull << lane)) |
-                               (bsh < 64 ? (((0x00000000ffffffffull << bsh) & E1) |
-                                            ((0x5555555500000000ull << bsh) & E2))
-                                         : 0ull);
+        uint64_t specR;
+        if (E1 == ~0ull && E2 == ~0ull) {  // every batch but the last ones of a chunk
+          specR = spec_full;
+        } else {
+          specR = (E1 & (2ull << lane)) | (bsh < 64 ? (((0x00000000ffffffffull << bsh) & E1) |
+                                                       ((0x5555555500000000ull << bsh) & E2))
+                                                    : 0ull);
+        }
         const uint64_t dupR = DUP & specR;
         const int fd = dupR ? __builtin_ctzll(dupR) : 64;
         const int mlen = inr ? prefix16(own, cb) : 0;
