@@ -22,6 +22,8 @@
 //                        same-slot collisions inside the batch with an LDS
 //                        write/read-back (collisions fall back to an in-order replay
 //                        of that batch).
+#include <type_traits>
+
 #include "lz77_device.h"
 
 namespace flate {
@@ -257,6 +259,8 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
     while (!done) {
       if (!sparse) {
         // =============================== dense batch ===============================
+        auto dense_batch = [&](auto interior_tag) {
+          constexpr bool INTERIOR = decltype(interior_tag)::value;
         STAMP(t0);
         const int B = s - 1;
         if (MULTI) {
@@ -264,9 +268,11 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
           if (first >= next_sweep) sweep(first);
         }
         const int q = B + lane;
-        const bool e1 = q >= 0 && q + 1 <= s_limit;  // may be inserted / probed with step 1
-        const bool e2 = q >= 0 && q + 2 <= s_limit;  // may be probed with step 2
-        const uint64_t E1 = __ballot(e1), E2 = __ballot(e2);
+        // INTERIOR: all 64 positions and their step-2 probes lie inside the chunk (every batch but
+        // the last of a chunk): e1, e2 and everything derived from them fold away
+        const bool e1 = INTERIOR || (q >= 0 && q + 1 <= s_limit);  // may be inserted / probed with step 1
+        const bool e2 = INTERIOR || (q >= 0 && q + 2 <= s_limit);  // may be probed with step 2
+        const uint64_t E1 = INTERIOR ? ~0ull : __ballot(e1), E2 = INTERIOR ? ~0ull : __ballot(e2);
         const uint32_t A1 = W + (uint32_t)q + 1;
         uint4 own = make_uint4(0, 0, 0, 0);
         uint32_t h = 0, old = 0;
@@ -572,6 +578,11 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
 #ifdef FLATE_LZ_STAMPS
         st_nb += 1;
 #endif
+        };
+        if (s - 1 >= 0 && s - 1 + 65 <= s_limit)
+          dense_batch(std::true_type{});
+        else
+          dense_batch(std::false_type{});
       } else {
         // =============================== sparse batch ==============================
         const int e = e_idx + lane;
