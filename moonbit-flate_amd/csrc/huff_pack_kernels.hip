@@ -985,14 +985,13 @@ __global__ __launch_bounds__(64) void huff_pack_kernel(HuffParams P) {
           const CodeBits oc = offset_code_of(tok_cur & ((1u << kLengthShift) - 1u));
           const uint32_t c1 = sh.lit_cl[kLengthCodesStart + lc.code];
           const uint32_t c2 = sh.off_cl[oc.code];
-          uint64_t bits = c1 & 0xffffu;
-          uint32_t mb = c1 >> 16;
-          bits |= (uint64_t)lc.extra << mb;
-          mb += lc.nextra;
-          bits |= (uint64_t)(c2 & 0xffffu) << mb;
-          mb += c2 >> 16;
-          bits |= (uint64_t)oc.extra << mb;
-          mb += oc.nextra;  // <= 48
+          // length code + extra (<= 15 + 5 bits) and offset code + extra (<= 15 + 13) each in one
+          // dword, joined by a single 64-bit shift
+          const uint32_t n1 = (c1 >> 16) + lc.nextra;
+          const uint32_t part1 = (c1 & 0xffffu) | (lc.extra << (c1 >> 16));
+          const uint32_t part2 = (c2 & 0xffffu) | (oc.extra << (c2 >> 16));
+          const uint64_t bits = part1 | ((uint64_t)part2 << n1);
+          const uint32_t mb = n1 + (c2 >> 16) + oc.nextra;  // <= 48
           hi = nb ? bits >> (64u - nb) : 0ull;
           lo |= bits << nb;
           nb += mb;
