@@ -170,16 +170,19 @@ FLATE_D void sink_emit(BitSink &S, uint64_t bits, uint32_t nb, int lane) {
 }
 
 // Wide form: every lane appends nb (<= 96) bits held in (lo, hi), in lane order.
-FLATE_D void sink_emit_wide(BitSink &S, uint64_t lo, uint64_t hi, uint32_t nb, int lane) {
+FLATE_D void sink_emit_wide(BitSink &S, uint64_t lo, uint32_t hi, uint32_t nb, int lane) {
   const uint32_t incl = wave_incl_scan(nb);
   const uint32_t total = rdlane(incl, 63);
   if (nb) {
     const uint64_t q = S.bitpos + (incl - nb);
     const uint32_t w = (uint32_t)(q >> 5);
     const uint32_t sh = (uint32_t)q & 31u;
+    // the 96 bits shifted left by sh < 32 into four dwords; (x >> 1) >> (31 - sh) is x >> (32 - sh)
+    // without the special case sh == 0
     const uint64_t v0 = lo << sh;
-    const uint64_t v1 = (hi << sh) | (sh ? (lo >> (64u - sh)) : 0ull);
-    const uint32_t d0 = (uint32_t)v0, d1 = (uint32_t)(v0 >> 32), d2 = (uint32_t)v1, d3 = (uint32_t)(v1 >> 32);
+    const uint32_t d0 = (uint32_t)v0, d1 = (uint32_t)(v0 >> 32);
+    const uint32_t d2 = (hi << sh) | (((uint32_t)(lo >> 32) >> 1) >> (31u - sh));
+    const uint32_t d3 = (hi >> 1) >> (31u - sh);
     if (d0) atomicOr(&S.ring[w & (kRing - 1)], d0);
     if (d1) atomicOr(&S.ring[(w + 1) & (kRing - 1)], d1);
     if (d2) atomicOr(&S.ring[(w + 2) & (kRing - 1)], d2);
@@ -942,7 +945,7 @@ __global__ __launch_bounds__(64) void huff_pack_kernel(HuffParams P) {
             lo |= (uint64_t)(c & 0xffffu) << nb;
             nb += c >> 16;
           }
-        sink_emit_wide(S, lo, 0, nb, lane);
+        sink_emit_wide(S, lo, 0u, nb, lane);
       }
     } else {
       // The walk over the implied token sequence was done by huff_hist_kernel: per tile, one byte
@@ -971,8 +974,8 @@ __global__ __launch_bounds__(64) void huff_pack_kernel(HuffParams P) {
         w.bytes = load_bytes4(w, (t + 1) * kTile + 4 * lane);
         const uint32_t tok_next = tok_of(m_next);
         const uint32_t m_next2 = t + 2 < ntiles ? tmeta[(t + 2) * 64 + lane] : 0u;
-        uint64_t lo = 0, hi = 0;
-        uint32_t nb = 0;
+        uint64_t lo = 0;
+        uint32_t hi = 0, nb = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           if ((m_cur >> k) & 1u) {  // at most three when a match follows: <= 45 bits
@@ -992,7 +995,7 @@ __global__ __launch_bounds__(64) void huff_pack_kernel(HuffParams P) {
           const uint32_t part2 = (c2 & 0xffffu) | (oc.extra << (c2 >> 16));
           const uint64_t bits = part1 | ((uint64_t)part2 << n1);
           const uint32_t mb = n1 + (c2 >> 16) + oc.nextra;  // <= 48
-          hi = nb ? bits >> (64u - nb) : 0ull;
+          hi = nb ? (uint32_t)(bits >> (64u - nb)) : 0u;  // (< 2^29: 48 + 45 - 64 bits)
           lo |= bits << nb;
           nb += mb;
         }
