@@ -88,15 +88,29 @@ def cpu_info():
     return {"nproc": os.cpu_count() or 1, "model": model}
 
 
-def pmc_traffic(name, key):
+def pmc_traffic(name, key, flate, args):
     """HBM bytes per launch from the rocprofv3 --pmc passes kept in profiles/ (FETCH_SIZE and
     WRITE_SIZE collected in separate passes, units/corrections as MI355X_MICROARCH.md prescribes:
-    see profiles/r02/README.md).  None when no pass was collected for this configuration."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r02", name)))
-        return int(d[key]["hbm_bytes_per_launch"])
-    except Exception:
-        return None
+    see profiles/r02/README.md) -- but only when that collection describes the code being timed:
+    the file carries the source hash of the library it was collected on (tools/traffic_reduce.py,
+    flate_hip_build_id) and the run must use the default launch options.  Returns
+    (bytes or None, info dict for the bench line)."""
+    tuned = bool(args.option) or args.no_guests
+    lib_id = flate.build_id()
+    for rnd in ("r03", "r02"):
+        path = os.path.join(ROOT, "profiles", rnd, name)
+        try:
+            d = json.load(open(path))[key]
+            val = int(d["hbm_bytes_per_launch"])
+        except Exception:
+            continue
+        src = {"file": "profiles/%s/%s" % (rnd, name), "collected_on_build": d.get("build_id"),
+               "git_head": d.get("git_head"), "this_build": lib_id}
+        if tuned or d.get("build_id") != lib_id:
+            src["traffic_stale"] = True  # other sources, or non-default launch options: not quoted
+            return None, src
+        return val, src
+    return None, {"file": None, "this_build": lib_id}
 
 
 def summarize(times_s):
@@ -340,29 +354,62 @@ def bench_deflate(args, env, host, d_in, in_off, n, blen):
         if b:
             split = {"lds_table_blocks": a, "l2_table_guest_blocks": b - a, "queued": b}
 
-    # exchange step alone, both forms (outside the timed region; N>1)
+    # Parity of the exchange step FIRST, on the buffer the timed region's last overlapped
+    # (wait=False) gather produced -- before anything else may write a gather buffer -- and then on
+    # two more overlapped steps (both output buffers, both orders of reuse), each checked right after
+    # its finish().  Rank 0 regenerates a strided sample of every rank's streams from their seeds.
+    gathered_verified = 0
+
+    def check_gathered(g, per_rank):
+        from oracle import pyoracle
+        cnt = 0
+        for r in range(world):
+            for i in range(0, n, max(1, n // per_rank)):
+                src = flate.synth(args.kind, 1, blen, first_stream=r * n + i)
+                if bytes(g.stream(r * n + i).cpu().numpy()) != pyoracle.deflate(src):
+                    raise SystemExit("PARITY FAILURE in the gathered buffer: rank %d stream %d" % (r, i))
+                cnt += 1
+        return cnt
+
+    check = gather and args.verify and not args.spliced and not args.no_cpu_baseline
+    if check:
+        if rank == 0:
+            gathered_verified += check_gathered(last["gathered"], 64)
+        for _ in range(2):  # untimed: the overlapped path again, every finished gather checked
+            step()
+            drain()
+            if rank == 0:
+                gathered_verified += check_gathered(last["gathered"], 8)
+        sync_all(env)
+
+    # exchange step alone, both forms (outside the timed region; N>1); its own buffer (buf=None):
+    # the buffers of the overlapped path above are not touched any more
     gather_info = "none"
     if gather:
-        gather_info = {"mode_in_timed_region": args.gather_mode, "overlapped_with_next_batch": True}
+        gather_info = {"mode_in_timed_region": args.gather_mode, "overlapped_with_next_batch": True,
+                       "gathered_parity_checked_streams": gathered_verified}
         g = last["gathered"]
         recv = int(g.sizes.sum() - g.sizes[rank])
         gather_info.update({"bytes_received_per_gpu": recv, "padded_bytes_per_rank": int(g.pad)})
         # (the timed region above is what `value` reports; a failure of this side measurement is
         # recorded, it must not cost the run its line)
         modes = (args.gather_mode,) + tuple(m for m in ("allgather", "sendrecv") if m != args.gather_mode)
+        side_buf = None
         for mode in modes:
             try:
                 ts = []
                 for _ in range(3):
                     sync_all(env)
                     t1 = time.perf_counter()
-                    shard.gather_compressed(dist, outs[last_i], out_off, buf=gbuf[0], plan=plan, mode=mode)
+                    sg = shard.gather_compressed(dist, outs[last_i], out_off, buf=side_buf, plan=plan, mode=mode)
+                    side_buf = sg.buf
                     sync_all(env)
                     ts.append(time.perf_counter() - t1)
                 gather_info[mode + "_ms"] = summarize(ts)
             except Exception as e:  # noqa: BLE001
                 gather_info[mode + "_error"] = "%s: %s" % (type(e).__name__, e)
                 break
+        del side_buf
         mins = [gather_info[m + "_ms"]["min"] for m in ("allgather", "sendrecv") if m + "_ms" in gather_info]
         if mins:
             best = min(mins)
@@ -370,54 +417,33 @@ def bench_deflate(args, env, host, d_in, in_off, n, blen):
                 "achieved_GBs": round(recv / (best * 1e-3) / 1e9, 2), "xgmi_peak_GBs": XGMI_PEAK_GBS,
                 "frac_of_xgmi": round(recv / (best * 1e-3) / 1e9 / XGMI_PEAK_GBS, 4)})
 
-    # cpu_baseline leg (rank 0, outside the timed region): the oracle compresses the same streams
-    # on the host cores; its output is also the checker.  N=1: every stream the oracle produced
-    # is compared with what the GPU wrote.  N>1: a strided sample of the GATHERED buffer (streams
-    # of every rank, regenerated from their seeds) is compared with the oracle.
+    # cpu_baseline leg (rank 0, outside the timed region), the SAME at every N so that the 1-, 2-,
+    # 4- and 8-GPU lines read side by side: the oracle compresses rank 0's own shard (the first
+    # --cpu-sample-streams streams of its 1 GiB) on the host cores (16 threads, and 1 thread on a
+    # smaller sample); every stream it produced is compared with what this GPU wrote.
     verified = 0
     cpu_baseline = None
     if rank == 0 and not args.no_cpu_baseline:
-        if world == 1:
-            g_cpu = out[:clen].cpu().numpy() if (args.verify and not args.spliced) else None
-            cpu_baseline, verified = cpu_leg(host, in_off, n, blen, args.cpu_sample_streams, g_cpu, out_off)
-            if args.spliced and args.verify:
-                from oracle import pyoracle
-                ns = min(n, 2048)
-                o1, nb1, b1 = eng.deflate_spliced(d_in[:ns * blen], in_off[:ns + 1])
-                ref, ref_off = pyoracle.deflate_spliced(host[:ns * blen], in_off[:ns + 1])
-                if bytes(o1[:nb1].cpu().numpy()) != ref or not (b1 == ref_off).all():
-                    raise SystemExit("PARITY FAILURE: spliced stream differs from the oracle")
-                verified = ns
-        elif gather and args.verify and not args.spliced:
+        g_cpu = outs[last_i][:clen].cpu().numpy() if (args.verify and not args.spliced) else None
+        cpu_baseline, verified = cpu_leg(host, in_off, n, blen, args.cpu_sample_streams, g_cpu, out_off)
+        if args.spliced and args.verify and world == 1:
             from oracle import pyoracle
-            g = last["gathered"]
-            per_rank = 64
-            cdt = 0.0
-            nbytes = 0
-            for r in range(world):
-                for i in range(0, n, max(1, n // per_rank)):
-                    src = flate.synth(args.kind, 1, blen, first_stream=r * n + i)
-                    t1 = time.perf_counter()
-                    want = pyoracle.deflate(src)
-                    cdt += time.perf_counter() - t1
-                    got = bytes(g.stream(r * n + i).cpu().numpy())
-                    if got != want:
-                        raise SystemExit("PARITY FAILURE in the gathered buffer: rank %d stream %d" % (r, i))
-                    verified += 1
-                    nbytes += blen
-            cpu_baseline = {"value": round(nbytes / cdt / 2**30, 4), "unit": "GiB/s", "cores": 1, "kind": "port",
-                            "sample": "%d streams of the gathered buffer (%d per rank, strided), oracle C restatement, "
-                                      "1 thread, %.2f s in the oracle" % (verified, verified // world, cdt),
-                            "host": cpu_info()}
+            ns = min(n, 2048)
+            o1, nb1, b1 = eng.deflate_spliced(d_in[:ns * blen], in_off[:ns + 1])
+            ref, ref_off = pyoracle.deflate_spliced(host[:ns * blen], in_off[:ns + 1])
+            if bytes(o1[:nb1].cpu().numpy()) != ref or not (b1 == ref_off).all():
+                raise SystemExit("PARITY FAILURE: spliced stream differs from the oracle")
+            verified = ns
+    verified += gathered_verified
 
     value = world * in_bytes * steps / dt / 2**30
     lz_ms = stage_ms["lz77_match"] / steps
     algo_bytes = in_bytes + clen  # B read + C written per stream, all streams
     achieved = algo_bytes / (lz_ms * 1e-3) / 1e9 if lz_ms > 0 else 0.0
     checked = ("bit-exact vs oracle (%d streams compared)" % verified) if verified else "parity not checked in this run"
-    traffic = None
-    if args.kind == "text" and n == 16384 and blen == 65536 and not args.no_guests:
-        traffic = pmc_traffic("lz77_traffic.json", "lz77_default_16384x65536_text")
+    traffic, traffic_src = None, None
+    if args.kind == "text" and n == 16384 and blen == 65536:
+        traffic, traffic_src = pmc_traffic("lz77_traffic.json", "lz77_default_16384x65536_text", flate, args)
     return {
         "metric": "GiB/s uncompressed throughput (encode), 64 KiB blocks, deflate-fast",
         "value": round(value, 3), "unit": "GiB/s", "n_gpus": world, "steps": steps,
@@ -439,7 +465,7 @@ def bench_deflate(args, env, host, d_in, in_off, n, blen):
         "roofline": {
             "bound": "hbm", "kernel": "lz77 match finder (resident + guest launch)", "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": traffic,
+            "traffic": traffic, "traffic_source": traffic_src,
         },
         "cpu_baseline": cpu_baseline,
     }
@@ -520,9 +546,9 @@ def bench_inflate(args, env, d_in, in_off, n, blen, host=None, steps=None, warmu
     clen = int(coff[-1])
     k_ms = ms / steps
     achieved = (n * blen + clen) / (k_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, traffic_src = None, None
     if args.kind == "text" and blen == 65536 and n == 131072 and not args.spliced:
-        traffic = pmc_traffic("inflate_traffic.json", "inflate_131072x65536_text")
+        traffic, traffic_src = pmc_traffic("inflate_traffic.json", "inflate_131072x65536_text", env["flate"], args)
     return {
         "metric": "GiB/s decompressed output (inflate), 64 KiB streams", "unit": "GiB/s",
         "value": round(world * n * blen * steps / dt / 2**30, 3), "n_gpus": world,
@@ -536,7 +562,7 @@ def bench_inflate(args, env, d_in, in_off, n, blen, host=None, steps=None, warmu
         "roofline": {"bound": "hbm", "kernel": "inflate_simt_kernel" if n > 2048 else "inflate_kernel",
                      "achieved": round(achieved, 2),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                     "traffic": traffic},
+                     "traffic": traffic, "traffic_source": traffic_src},
         "cpu_baseline": cpu_baseline,
         **({"end_to_end_host_pointers": host_leg} if host_leg else {})}
 
@@ -629,6 +655,7 @@ def extra_legs(args, env):
             verified += 1
     lz_ms = stage["lz77_match"] / steps
     ach = (n * blen + clen) / (lz_ms * 1e-3) / 1e9
+    c3_traffic, c3_src = pmc_traffic("lz77_traffic.json", "lz77_default_4096x262144_text", flate, args)
     extra["config3_1GiB_of_256KiB_streams"] = {
         "metric": "GiB/s uncompressed throughput (encode), 256 KiB streams, deflate-fast",
         "value": round(n * blen * steps / dt / 2**30, 3), "unit": "GiB/s", "steps": steps,
@@ -639,7 +666,7 @@ def extra_legs(args, env):
         "roofline": {"bound": "hbm", "kernel": "lz77 match finder, multi-window (resident + guest launch)",
                      "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(ach / HBM_PEAK_GBS, 5),
-                     "traffic": pmc_traffic("lz77_traffic.json", "lz77_default_4096x262144_text")},
+                     "traffic": c3_traffic, "traffic_source": c3_src},
     }
     del host, d_in, out
     torch.cuda.empty_cache()

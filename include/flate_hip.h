@@ -78,9 +78,18 @@ int flate_hip_set_stream(flate_hip_ctx *ctx, void *hip_stream);
  *   "inflate_simt_min_streams"  inflate batches at least this large decode one stream per LANE
  *                        (64 per wavefront) instead of one per wavefront (default 2049)
  *   "inflate_lanes"      streams per wavefront of that decoder: 0 = chosen from the batch size
- *                        (default), or 16 / 32 / 64 */
+ *                        (default), or 16 / 32 / 64
+ *   "spin_limit_polls"   the persistent kernels' waits (a window that another block is still
+ *                        producing, the gate of an overlapped sub-batch) give up after this many
+ *                        polls and the call returns FLATE_HIP_E_INTERNAL (default 8 Mi polls,
+ *                        several seconds of a running wave; time spent preempted does not count)
+ *   "debug_drop_window_push"  test hook: k > 0 loses the k-th window hand-over of the next
+ *                        multi-window launch, so that the bounded wait can be exercised */
 int flate_hip_set_option(flate_hip_ctx *ctx, const char *name, int64_t value);
 const char *flate_hip_strerror(int code);
+/* Hash of the sources this library was built from (moonbit-flate_amd/build.py: source_hash):
+ * measurement files under profiles/ carry the id of the build they were collected on. */
+const char *flate_hip_build_id(void);
 /* Text of the last HIP runtime error seen by this ctx ("" if none). */
 const char *flate_hip_last_hip_error(const flate_hip_ctx *ctx);
 

@@ -13,7 +13,7 @@ EXPORTS = [
     "flate_hip_last_hip_error", "flate_hip_deflate_bound", "flate_hip_deflate_fast_batch",
     "flate_hip_lz77_matches", "flate_hip_inflate_batch", "flate_hip_deflate_fast_spliced",
     "flate_hip_inflate_spliced", "flate_hip_set_profiling", "flate_hip_last_resident_share",
-    "flate_hip_last_timing", "flate_hip_stage_name", "flate_hip_synth_fill",
+    "flate_hip_last_timing", "flate_hip_stage_name", "flate_hip_synth_fill", "flate_hip_build_id",
 ]
 
 _lib = None
@@ -69,5 +69,7 @@ def load():
     L.flate_hip_synth_fill.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64,
                                        vp, C.c_int]
     L.flate_hip_synth_fill.restype = C.c_int
+    L.flate_hip_build_id.argtypes = []
+    L.flate_hip_build_id.restype = C.c_char_p
     _lib = L
     return L

@@ -14,6 +14,21 @@ SOURCES = ["lz77_kernels.hip",  "huff_pack_kernels.hip", "compact_kernels.hip",
 HEADERS = ["flate_common.h", "flate_kernels.h", "lz77_device.h", os.path.join(ROOT, "include", "flate_hip.h")]
 
 
+def source_hash():
+    """16 hex digits over every source and header the library is built from (name + contents).
+    Compiled into the library (flate_hip_build_id) and written beside every PMC collection in
+    profiles/, so that a bench line can tell whether a collected figure describes this code."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, s) for s in SOURCES] + \
+            [x if os.path.isabs(x) else os.path.join(CSRC, x) for x in HEADERS]
+    for f in sorted(files, key=os.path.basename):
+        if os.path.exists(f):
+            h.update(os.path.basename(f).encode() + b"\0")
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _stale():
     if not os.path.exists(LIB_PATH):
         return True
@@ -30,6 +45,7 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
+           "-DFLATE_HIP_BUILD_ID=\"%s\"" % source_hash(),
            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + srcs + ["-o", LIB_PATH, "-lpthread"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

@@ -42,15 +42,15 @@ __global__ __launch_bounds__(1024) void scan_sizes_kernel(CompactParams P) {
 
 // Gate of a sub-batch of the entropy stage: the match finder (still running on other HIP streams)
 // counts the streams of the sub-batch it has finished; this one-lane kernel returns when all of
-// them are there.  The spin is bounded (about 4 s of the 100 MHz real-time counter): a count that
-// never arrives becomes an error code, not a hang.
-__global__ void wait_count_kernel(const uint32_t *counter, uint32_t target, int *status) {
-  const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-  for (;;) {
+// them are there.  The spin is bounded by a number of polls (spin_limit; a wave that is not
+// running -- preempted, time-sliced with another process -- does not count against it): a count
+// that never arrives becomes an error code (kStatusGateTimeout), not a hang.
+__global__ void wait_count_kernel(const uint32_t *counter, uint32_t target, int *status, uint32_t spin_limit) {
+  for (uint32_t polls = 0;; ++polls) {
     const uint32_t v = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (v >= target) break;
-    if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) {
-      atomicExch(status, -8);  // FLATE_HIP_E_INTERNAL
+    if (polls >= spin_limit) {
+      atomicExch(status, kStatusGateTimeout);
       break;
     }
     __builtin_amdgcn_s_sleep(32);

@@ -86,6 +86,10 @@ struct flate_hip_ctx {
   // and group g is compressed while group g+1 is copied in and the output of group g-1 is copied
   // out (two copy threads on two non-blocking streams).  0 = one copy in, compress, one copy out.
   int host_groups = 4;
+  // bounded waits of the persistent kernels (uq_pop, wait_count_kernel): polls before giving up
+  // (a poll is one relaxed load + s_sleep, >= 0.4 us; a wave that is not running does not count)
+  uint32_t spin_limit = 8u << 20;
+  uint32_t inject_drop_push = 0;  // test hook: the k-th window hand-over (1-based) is dropped
   hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
 };
 
@@ -219,7 +223,7 @@ int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, cons
     HIP_TRY(c, hipMemcpyAsync(c->d_ids32.p, pl.ids32.data(), pl.ids32.size() * 4,
                               hipMemcpyHostToDevice, c->stream));
 
-  LzParams P;
+  LzParams P{};  // (value-initialised: a field added later must never reach a kernel as stack garbage)
   P.in = d_in;
   P.in_off = (const uint64_t *)c->d_in_off.p;
   P.chunk_base = (const uint32_t *)c->d_chunk_base.p;
@@ -235,6 +239,10 @@ int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, cons
   P.queue = nullptr;
   P.queue_end = 0;
   P.done = overlap_sub ? (uint32_t *)c->d_done.p : nullptr;
+  P.done_cap = overlap_sub ? kDoneCounters : 0u;
+  P.gtable_blocks = 0;
+  P.spin_limit = c->spin_limit;
+  P.inject_drop_push = c->inject_drop_push;
   P.taken = nullptr;
   P.uq_ready = nullptr;
   P.uq_ctr = nullptr;
@@ -244,8 +252,8 @@ int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, cons
   P.status = (int *)c->d_status.p;
   c->last_count[0] = c->last_count[1] = 0;
   // multi-window streams of a persistent launch run one window at a time (see uq_run): the
-  // streams' tables rest in global memory between windows (32 KiB each; beyond 4 GiB of them the
-  // launch falls back to one block per stream at a time; the ready word limits it to 2^17 - 2 streams)
+  // streams' tables rest in global memory between windows (32 KiB each; the ready word limits it
+  // to 2^17 - 2 streams; more than that, or no memory for the scratch: whole-stream scheduling)
   uint32_t uq_units = 0;
   const size_t n32 = pl.ids32.size();
   const bool use_uq = c->window_units && c->guest_blocks > 0 && n32 >= c->guest_min &&
@@ -256,9 +264,15 @@ int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, cons
     if (units < 0xffffffffull) uq_units = (uint32_t)units;
   }
   if (uq_units) {
-    if ((rc = ensure(c, c->d_uq_ready, (size_t)uq_units * 4 + 64))) return rc;
-    if ((rc = ensure(c, c->d_uq_tables, n32 * (size_t)kTableSize * 2 + 64))) return rc;
-    if ((rc = ensure(c, c->d_uq_sweep, n32 * 4 + 64))) return rc;
+    // (grow-only scratch, 32 KiB per multi-window stream: when the device cannot give it, the
+    // launch falls back to whole-stream scheduling, which needs none)
+    if (ensure(c, c->d_uq_ready, (size_t)uq_units * 4 + 64) != FLATE_HIP_OK ||
+        ensure(c, c->d_uq_tables, n32 * (size_t)kTableSize * 2 + 64) != FLATE_HIP_OK ||
+        ensure(c, c->d_uq_sweep, n32 * 4 + 64) != FLATE_HIP_OK) {
+      (void)hipGetLastError();
+      c->hip_err.clear();
+      uq_units = 0;
+    }
   }
   P.done_shift = 0;
   while (overlap_sub && (1u << P.done_shift) < overlap_sub) ++P.done_shift;  // (a power of two)
@@ -305,6 +319,7 @@ int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, cons
         // fork: resident (LDS-table) and guest (L2-table) blocks pull streams from one queue
         LzParams G = P;
         G.gtables = c->d_gtables.p;
+        G.gtable_blocks = (uint32_t)c->guest_blocks;  // d_gtables holds exactly this many tables
         G.queue = (uint32_t *)c->d_queue.p + queue_slot;
         G.queue_end = count;
         c->last_count[queue_slot] = count;
@@ -371,6 +386,11 @@ const char *flate_hip_strerror(int code) {
     default: return "unknown error";
   }
 }
+
+#ifndef FLATE_HIP_BUILD_ID
+#define FLATE_HIP_BUILD_ID "unknown"
+#endif
+const char *flate_hip_build_id(void) { return FLATE_HIP_BUILD_ID; }
 
 const char *flate_hip_last_hip_error(const flate_hip_ctx *ctx) {
   return ctx ? ctx->hip_err.c_str() : "";
@@ -497,6 +517,10 @@ int flate_hip_set_option(flate_hip_ctx *c, const char *name, int64_t value) {
     c->overlap_sub = (int)value;
   } else if (k == "overlap_resident_blocks" && value > 0 && value <= 65536) {
     c->overlap_resident = (uint32_t)value;
+  } else if (k == "spin_limit_polls" && value > 0 && value <= 0x7fffffff) {
+    c->spin_limit = (uint32_t)value;
+  } else if (k == "debug_drop_window_push" && value >= 0 && value <= 0x7fffffff) {
+    c->inject_drop_push = (uint32_t)value;
 
   } else {
     return FLATE_HIP_E_INVALID;
@@ -590,8 +614,10 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
   }
   const uint32_t J = overlap ? (n + sub - 1) / sub : 1u;
   if (overlap) {
-    if ((rc = ensure(c, c->d_done, 64 * 4 + 16))) return rc;
-    HIP_TRY(c, hipMemsetAsync(c->d_done.p, 0, 64 * 4 + 16, c->stream));
+    // the counters the match finder increments (P.done + (q >> done_shift), q < n): J of them
+    if (J > kDoneCounters) return FLATE_HIP_E_INTERNAL;
+    if ((rc = ensure(c, c->d_done, kDoneCounters * 4 + 16))) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->d_done.p, 0, kDoneCounters * 4 + 16, c->stream));
     while (c->ent_ev.size() < 2 * (size_t)J) {
       hipEvent_t e = nullptr;
       HIP_TRY(c, hipEventCreate(&e));
@@ -603,7 +629,7 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
   // and memset the entropy kernels depend on
   if (overlap) (void)hipStreamWaitEvent(c->ent_stream, c->ev_fork, 0);
 
-  HuffParams H;
+  HuffParams H{};
   H.in = d_in;
   H.in_off = (const uint64_t *)c->d_in_off.p;
   H.chunk_base = (const uint32_t *)c->d_chunk_base.p;
@@ -626,7 +652,7 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
   H.n_streams = n;
   H.compat_go = (flags & FLATE_HIP_COMPAT_GO) ? 1u : 0u;
   H.sid0 = 0;
-  CompactParams C;
+  CompactParams C{};
   C.out_len = (const uint64_t *)c->d_out_len.p;
   C.out_off = (uint64_t *)c->d_out_off.p;
   C.out_cap = out_cap;
@@ -639,13 +665,13 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
     // the sub-batches in queue order on ent_stream, each behind its gate; the match finder keeps
     // running on c->stream / guest_stream
     uint32_t *done = (uint32_t *)c->d_done.p;
-    C.carry = (uint64_t *)((uint8_t *)c->d_done.p + 64 * 4);
+    C.carry = (uint64_t *)((uint8_t *)c->d_done.p + kDoneCounters * 4);
     for (uint32_t j = 0; j < J; ++j) {
       const uint32_t first = j * sub;
       if (first >= n) break;
       const uint32_t cnt = n - first < sub ? n - first : sub;
       hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(1), 0, c->ent_stream, done + j, cnt,
-                         (int *)c->d_status.p);
+                         (int *)c->d_status.p, c->spin_limit);
       if (c->profiling) (void)hipEventRecord(c->ent_ev[2 * j], c->ent_stream);
       H.sid0 = first;
       C.first = first;
@@ -665,7 +691,7 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
     if (!spliced) {
       hipLaunchKernelGGL(scan_sizes_kernel, dim3(1), dim3(1024), 0, c->stream, C);
     } else {
-      SpliceParams S;
+      SpliceParams S{};
       S.sum = (const uint64_t *)c->d_slot_off.p;
       S.stream_bit = (uint64_t *)c->d_out_off.p;
       S.total_bytes = (uint64_t *)c->d_out_len.p + n;  // (d_out_len has n + 1 slots)
@@ -689,8 +715,13 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
   HIP_TRY(c, hipMemcpyAsync(&c->h_status_word, c->d_status.p, 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (c->h_status_word) {
-    if (c->h_status_word == FLATE_HIP_E_INTERNAL) {
-      c->hip_err = "a match-finder block waited for a window that was never handed over";
+    if (c->h_status_word == kStatusUqTimeout || c->h_status_word == kStatusGateTimeout ||
+        c->h_status_word == kStatusBadIndex) {
+      c->hip_err = c->h_status_word == kStatusUqTimeout
+                       ? "a match-finder block waited for a window that was never handed over"
+                       : (c->h_status_word == kStatusGateTimeout
+                              ? "the entropy stage's gate waited for a sub-batch the match finder never finished"
+                              : "a match-finder block was handed an index outside its scratch");
       return FLATE_HIP_E_INTERNAL;
     }
     if (c->h_status_word <= -0x100000) {  // encoder self-check (huff_pack_kernel): -(0x100000 + stream)
@@ -954,7 +985,7 @@ int flate_hip_lz77_matches(flate_hip_ctx *c, const uint8_t *in, const uint64_t *
                             hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(&c->h_status_word, c->d_status.p, 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if (c->h_status_word) return c->h_status_word;
+  if (c->h_status_word) return c->h_status_word <= kStatusUqTimeout ? FLATE_HIP_E_INTERNAL : c->h_status_word;
   for (uint32_t k = 0; k <= pl.n_chunks; ++k) chunk_rec_off[k] = (uint64_t)k * kMatchCapPerChunk;
   const hipMemcpyKind kind = dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
   HIP_TRY(c, hipMemcpyAsync(recs, c->d_matches.p, (size_t)pl.n_chunks * kMatchCapPerChunk * 8, kind,
@@ -1001,7 +1032,7 @@ static int inflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
   if ((rc = ensure(c, c->d_ierr, (size_t)n * 8 + 8))) return rc;
   HIP_TRY(c, hipMemcpyAsync(c->d_in_off.p, in_off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->d_slot_off.p, out_off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
-  InfParams I;
+  InfParams I{};
   I.in = d_in;
   I.in_off = (const uint64_t *)c->d_in_off.p;
   I.out = d_out;

@@ -9,6 +9,13 @@ namespace flate {
 // deflate.mbt:236-277): every full 65535-byte window plus a final partial window
 // of >= 128 bytes.  chunk_base[i] .. chunk_base[i+1] are stream i's chunks; chunk c
 // owns match records [c * kMatchCapPerChunk, (c+1) * kMatchCapPerChunk).
+// counters of the overlapped entropy stage (flate_hip_ctx::d_done): at most this many sub-batches
+constexpr uint32_t kDoneCounters = 64;
+// device-side status words that the host turns into FLATE_HIP_E_INTERNAL with a message
+constexpr int kStatusUqTimeout = -8;     // uq_pop: the unit with my ticket was never pushed
+constexpr int kStatusGateTimeout = -9;   // wait_count_kernel: a sub-batch was never finished
+constexpr int kStatusBadIndex = -10;     // an index outside the scratch it addresses (never expected)
+
 struct LzParams {
   const uint8_t *in;
   const uint64_t *in_off;      // n_streams + 1
@@ -29,6 +36,10 @@ struct LzParams {
   // sub-batch of the queue (null = off); incremented after the stream's records are visible
   uint32_t *done;
   uint32_t done_shift;
+  uint32_t done_cap;       // counters behind `done` (an index beyond them sets kStatusBadIndex)
+  uint32_t gtable_blocks;  // tables behind `gtables` (a guest block beyond them does nothing)
+  uint32_t spin_limit;     // polls before a bounded wait gives up
+  uint32_t inject_drop_push;  // test hook (option debug_drop_window_push): drop that hand-over
   // measurement aid: the launch counts the streams it took from the queue here (null = off)
   uint32_t *taken;
   // Window-granular scheduling of multi-window streams (persistent MULTI launches): the unit of
@@ -114,7 +125,7 @@ __global__ void uq_init_kernel(uint32_t *ready, uint32_t *ctr, uint32_t n_stream
 __global__ void scan_sizes_kernel(CompactParams P);
 // spins (bounded) until *counter >= target: gates a sub-batch of the entropy stage on the match
 // finder that is still running on another stream
-__global__ void wait_count_kernel(const uint32_t *counter, uint32_t target, int *status);
+__global__ void wait_count_kernel(const uint32_t *counter, uint32_t target, int *status, uint32_t spin_limit);
 __global__ void inflate_kernel(InfParams P);
 template <int LPW>
 __global__ void inflate_simt_kernel(InfParams P);

@@ -715,8 +715,12 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
 // release covers the whole wavefront's stores: the wait the compiler emits in front of the L2
 // write-back is the wave's vmcnt, and a wave barrier precedes the call.
 FLATE_D void stream_done_lane0(const LzParams &P, uint32_t q) {
-  if (P.done)
-    __hip_atomic_fetch_add(P.done + (q >> P.done_shift), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (!P.done) return;
+  const uint32_t k = q >> P.done_shift;
+  if (k < P.done_cap)  // (the host sizes the counters for exactly this; anything else is a bug, not a fault)
+    __hip_atomic_fetch_add(P.done + k, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  else
+    atomicExch(P.status, kStatusBadIndex);
 }
 
 // ---------------------------------------------------------------------------------
@@ -727,8 +731,8 @@ FLATE_D void stream_done_lane0(const LzParams &P, uint32_t q) {
 // block pops the next ready unit {stream, window} from one FIFO, runs that window, and pushes the
 // stream's next window to the back.  All first windows are ready at the start, so the order is
 // breadth-first and every slot stays busy until the last window time.  Between two of its
-// windows a stream's table rests in global memory (uq_tables, 32 KiB per stream): LDS-table blocks
-// load it into LDS and store it back, guest blocks work on it in place.
+// windows a stream's table rests in global memory (uq_tables, 32 KiB per stream): every block loads
+// it into its own working table (LDS, or the guest block's slice of gtables) and stores it back.
 // ---------------------------------------------------------------------------------
 struct UqUnit {
   uint32_t q;  // queue entry (index into stream_ids)
@@ -751,7 +755,10 @@ FLATE_D UqUnit uq_pop(const LzParams &P, const uint32_t push_word, int lane) {
       stream_done_lane0(P, push_word & 0x7fffffffu);
     } else if (push_word != 0) {
       const uint32_t k = __hip_atomic_fetch_add(P.uq_ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(P.uq_ready + k, push_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (test hook: option debug_drop_window_push loses one hand-over, so that the bounded wait
+      // below can be shown to end in an error code and not in a hang)
+      if (k + 1u - P.queue_end != P.inject_drop_push)
+        __hip_atomic_store(P.uq_ready + k, push_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     t = __hip_atomic_fetch_add(P.uq_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -759,16 +766,17 @@ FLATE_D UqUnit uq_pop(const LzParams &P, const uint32_t push_word, int lane) {
   const uint32_t units = P.uq_units;
   uint32_t v = 0;
   if (t < units) {
-    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-    for (;;) {
+    // bounded by polls, not by wall time: a wave that is preempted or time-sliced with another
+    // process does not run out its bound while its producer is not running either
+    for (uint32_t polls = 0;; ++polls) {
       uint32_t x = 0;
       if (lane == 0) x = __hip_atomic_load(P.uq_ready + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       v = (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
       if (v != 0) break;
-      if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) break;  // ~4 s of the 100 MHz counter
+      if (polls >= P.spin_limit) break;
       __builtin_amdgcn_s_sleep(16);
     }
-    if (v == 0 && lane == 0) atomicExch(P.status, -8);  // FLATE_HIP_E_INTERNAL: gave up
+    if (v == 0 && lane == 0) atomicExch(P.status, kStatusUqTimeout);  // gave up: FLATE_HIP_E_INTERNAL
     // acquire (one lane: the invalidate is per CU) before anyone reads the producer's payload
     if (lane == 0) (void)__hip_atomic_load(P.uq_ready + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -877,6 +885,7 @@ __global__ __launch_bounds__(64) void lz77_wave_kernel(LzParams P) {
 // their XCD -- and pulls streams from a queue.
 template <bool MULTI>
 __global__ __launch_bounds__(64) void lz77_guest_kernel(LzParams P) {
+  if (blockIdx.x >= P.gtable_blocks) return;  // (gtables holds one table per block of this launch)
   uint16_t *table = reinterpret_cast<uint16_t *>(P.gtables) + (size_t)blockIdx.x * kTableSize;
   const int lane = threadIdx.x;
   uint32_t *tags = nullptr;

@@ -31,6 +31,11 @@ class FlateError(RuntimeError):
         self.code = code
 
 
+def build_id():
+    """Source hash compiled into the loaded library (see build.source_hash)."""
+    return _lib.load().flate_hip_build_id().decode()
+
+
 def deflate_bound(n):
     return int(_lib.load().flate_hip_deflate_bound(int(n)))
 

@@ -268,6 +268,31 @@ def test_overlapped_entropy_stage_is_bit_exact(oracle):
         e.close()
 
 
+def test_lost_window_handover_is_an_error_not_a_hang(oracle):
+    # window-granular scheduling: a block waits (bounded) for the unit with its ticket.  The test
+    # hook drops one hand-over; the call must come back with FLATE_HIP_E_INTERNAL and a message that
+    # names the wait -- and the engine must work again afterwards.
+    n, blen = 24, 200000
+    data = flate.synth("text", n, blen, first_stream=7000)
+    off = flate.uniform_offsets(n, blen)
+    e = flate.FlateEngine(0)
+    try:
+        e.set_option("guest_min_streams", 1)
+        e.set_option("guest_blocks", 8)
+        e.set_option("resident_blocks", 8)
+        e.set_option("spin_limit_polls", 20000)
+        e.set_option("debug_drop_window_push", 3)
+        with pytest.raises(flate.FlateError) as ei:
+            e.deflate_batch(data, off)
+        assert ei.value.code == -8 and "never handed over" in str(ei.value)
+        e.set_option("debug_drop_window_push", 0)
+        out, out_off = e.deflate_batch(data, off)
+        for i in range(0, n, 5):
+            assert bytes(out[int(out_off[i]):int(out_off[i + 1])]) == oracle.deflate(data[i * blen:(i + 1) * blen]), i
+    finally:
+        e.close()
+
+
 def test_host_pointer_pipeline_matches_single_pass(oracle):
     # host-pointer calls on large batches are pipelined over groups of streams (option
     # host_pipeline_groups): same bytes and the same index as one pass, and as the oracle

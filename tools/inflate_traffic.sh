@@ -9,7 +9,8 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc $ctr -d gpurun_out/$tag/$ctr -o p --output-format csv -- python3 bench.py --mode inflate --streams $n --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/$tag/$ctr.log 2>&1
 done
 python3 - <<PY
-import collections, csv, glob, json
+import collections, csv, glob, json, os, sys, importlib
+sys.path.insert(0, os.getcwd())
 def per_kernel(path, counter):
     per = collections.defaultdict(float); names = {}
     for f in glob.glob(path + "/**/*counter_collection.csv", recursive=True):
@@ -20,7 +21,8 @@ def per_kernel(path, counter):
     for k, v in per.items(): agg[names[k]].append(v)
     return {k: sum(v) / len(v) for k, v in agg.items()}
 fs, ws = per_kernel("gpurun_out/$tag/FETCH_SIZE", "FETCH_SIZE"), per_kernel("gpurun_out/$tag/WRITE_SIZE", "WRITE_SIZE")
-out = {}
+out = {"build_id": importlib.import_module("moonbit-flate_amd").build_id(),
+       "git_head": os.environ.get("FLATE_GIT_HEAD", "unknown")}
 for k in fs:
     if "inflate" in k:
         out[k] = {"FETCH_SIZE_bytes_raw": int(fs[k] * 1024), "WRITE_SIZE_bytes": int(ws.get(k, 0) * 1024)}

@@ -37,8 +37,13 @@ for k in sorted(set(fs) | set(ws)):
 lz = sum(v["hbm_bytes_per_launch"] for k, v in kern.items() if "lz77" in k)
 step = sum(v["hbm_bytes_per_launch"] for v in kern.values())
 algo = n * blen + clen
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import importlib
+build_id = importlib.import_module("moonbit-flate_amd").build_id()
 print(json.dumps({
     "workload": "%d x %d B S-text streams" % (n, blen), "algorithmic_bytes": algo,
+    # what this collection describes: bench.py quotes it only for a library with the same id
+    "build_id": build_id, "git_head": os.environ.get("FLATE_GIT_HEAD", "unknown"),
     "queue_split": {"lds_table_blocks": K, "l2_table_guest_blocks": n - K,
                     "note": "split of the shared queue in an unprofiled run, fixed for the PMC passes "
                             "(option profile_split_streams) because rocprofv3 serialises the two kernels"},
