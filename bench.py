@@ -172,6 +172,10 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="skip the exchange step (N>1)")
     ap.add_argument("--gather-mode", default="allgather", choices=["allgather", "sendrecv"],
                     help="exchange inside the timed region: padded all_gather_into_tensor or grouped isend/irecv")
+    ap.add_argument("--native-gather", action="store_true",
+                    help="N>1, nccl: after the timed region also run the exchange through the C ABI "
+                         "(flate_hip_gather_compressed on the library's own RCCL communicator), both forms, "
+                         "checked against the torch.distributed result")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-streams", type=int, default=16384,
                     help="streams of the workload the CPU oracle is timed on (about 10 CPU-seconds per GiB)")
@@ -410,6 +414,27 @@ def bench_deflate(args, env, host, d_in, in_off, n, blen):
                 gather_info[mode + "_error"] = "%s: %s" % (type(e).__name__, e)
                 break
         del side_buf
+        if args.native_gather and env["cuda"] and dist.get_backend() == "nccl":
+            # the same exchange through include/flate_hip.h (what a MoonBit / C++ host calls)
+            try:
+                comm = shard.NativeComm(eng, rank, world, dist)
+                nat = {}
+                for mode in ("allgather", "sendrecv"):
+                    ts = []
+                    for _ in range(3):
+                        sync_all(env)
+                        t1 = time.perf_counter()
+                        ng = comm.gather(outs[last_i], out_off, mode=mode)
+                        sync_all(env)
+                        ts.append(time.perf_counter() - t1)
+                    for j in range(0, world * n, max(1, world * n // 64)):
+                        if not torch.equal(ng.stream(j), g.stream(j)):
+                            raise SystemExit("C-ABI exchange differs from torch.distributed at stream %d" % j)
+                    nat[mode + "_ms"] = summarize(ts)
+                comm.close()
+                gather_info["c_abi"] = nat
+            except Exception as e:  # noqa: BLE001
+                gather_info["c_abi_error"] = "%s: %s" % (type(e).__name__, e)
         mins = [gather_info[m + "_ms"]["min"] for m in ("allgather", "sendrecv") if m + "_ms" in gather_info]
         if mins:
             best = min(mins)

@@ -37,6 +37,9 @@ typedef struct flate_hip_ctx flate_hip_ctx;
 #define FLATE_HIP_E_TOO_LARGE (-6)      /* stream >= 2 GiB - 128 KiB (buffer_reset,
                                            deflate-fast.mbt:55: shift_offsets not built) */
 #define FLATE_HIP_E_UNEXPECTED_EOF (-7) /* inflate: err_unexpected_eof (inflate.mbt:781) */
+#define FLATE_HIP_E_AGAIN (-9)          /* flate_hip_gather_end: a shard outgrew the agreed pad; the
+                                           plan has been raised on every rank: repeat this batch
+                                           with flate_hip_gather_compressed                      */
 #define FLATE_HIP_E_INTERNAL (-8)       /* encoder self-check failed (the reference abort()s on its
                                            invariants, deflate.mbt:111, huffman-code.mbt:118,232):
                                            packed bits != the size computed before packing;
@@ -159,6 +162,56 @@ int flate_hip_deflate_fast_spliced(flate_hip_ctx *ctx, const uint8_t *in,
                                    const uint64_t *in_off, uint32_t n_streams, uint8_t *out,
                                    uint64_t out_cap, uint64_t *out_len, uint64_t *bit_off,
                                    uint32_t flags);
+
+/* -- exchange step (multi-GPU) ---------------------------------------------------
+ * SURVEY 8(e) / section 5; no counterpart in the reference (single-threaded, no communication
+ * layer).  Independent streams shard by contiguous index range, one process and one ctx per
+ * GPU, no collective in the compress path; this step concatenates the compressed shards on
+ * every rank over RCCL (xGMI inside a node).  A host in the reference's language drives it
+ * through these entry points; moonbit-flate_amd/shard.py is a thin caller.
+ *
+ * A flate_hip_comm wraps one RCCL communicator (created here from a unique id that rank 0
+ * makes and the host distributes -- or an existing ncclComm_t) together with the exchange's
+ * own HIP stream and the sticky plan {pad, largest stream count} all ranks agree on. */
+typedef struct flate_hip_comm flate_hip_comm;
+#define FLATE_HIP_UNIQUE_ID_BYTES 128
+#define FLATE_HIP_GATHER_ALLGATHER 0u /* payloads padded to `pad`, one ncclAllGather; rank r at out + r*pad */
+#define FLATE_HIP_GATHER_SENDRECV 1u  /* exact sizes, grouped ncclSend/ncclRecv to all peers at once;
+                                         shards back to back in rank order                          */
+int flate_hip_comm_unique_id(uint8_t id[FLATE_HIP_UNIQUE_ID_BYTES]);
+int flate_hip_comm_init(flate_hip_ctx *ctx, const uint8_t id[FLATE_HIP_UNIQUE_ID_BYTES], int rank,
+                        int world, flate_hip_comm **comm);
+/* An existing ncclComm_t (passed as void*, not owned) of the ctx's device. */
+int flate_hip_comm_wrap(flate_hip_ctx *ctx, void *nccl_comm, int rank, int world, flate_hip_comm **comm);
+void flate_hip_comm_destroy(flate_hip_comm *comm);
+/* The plan: payload slot size of the padded form (a multiple of 1 MiB) and the largest per-rank
+ * stream count.  It only grows.  set_plan must be given the same values on every rank. */
+int flate_hip_comm_plan(flate_hip_comm *comm, uint64_t *pad, uint32_t *max_streams);
+int flate_hip_comm_set_plan(flate_hip_comm *comm, uint64_t pad, uint32_t max_streams);
+/* Host arithmetic of the layout alone (no GPU, no RCCL): pad = largest shard rounded up to
+ * pad_to, rank_base[r] = where rank r's shard starts in out, *out_bytes = room out needs. */
+int flate_hip_gather_layout(uint32_t world, const uint64_t *rank_bytes, uint64_t pad_to, uint32_t mode,
+                            uint64_t *pad, uint64_t *rank_base, uint64_t *out_bytes);
+/* Blocking exchange.  local (device, local_cap readable bytes) holds this rank's k streams back
+ * to back, local_off[k+1] (host) their offsets (local_off[0] = 0) -- what
+ * flate_hip_deflate_fast_batch returned.  On return out (device) holds every rank's shard and,
+ * for the *total_streams streams of all ranks in rank-major order, stream j is
+ * out[stream_off[j] .. + stream_len[j]) (host arrays of index_cap entries).  Every rank must
+ * call with the same mode; FLATE_HIP_E_OUT_TOO_SMALL is returned on every rank if any rank's out
+ * is too small (decided from gathered values: no rank is left waiting in a collective). */
+int flate_hip_gather_compressed(flate_hip_comm *comm, const uint8_t *local, uint64_t local_cap,
+                                const uint64_t *local_off, uint32_t k, uint8_t *out, uint64_t out_cap,
+                                uint64_t *stream_off, uint64_t *stream_len, uint64_t index_cap,
+                                uint64_t *total_streams, uint32_t mode);
+/* Overlapped exchange (padded form, plan required: one blocking call or set_plan first).
+ * begin returns at once: the exchange starts when the work queued so far on the ctx's stream
+ * (the compression that wrote local) is done and runs on the communicator's own stream, beside
+ * the next batch's compression.  local and out must stay untouched until end, which waits for
+ * the exchange and fills the index; FLATE_HIP_E_AGAIN = a shard outgrew the pad (raised now). */
+int flate_hip_gather_begin(flate_hip_comm *comm, const uint8_t *local, uint64_t local_cap,
+                           const uint64_t *local_off, uint32_t k, uint8_t *out, uint64_t out_cap);
+int flate_hip_gather_end(flate_hip_comm *comm, uint64_t *stream_off, uint64_t *stream_len,
+                         uint64_t index_cap, uint64_t *total_streams);
 
 /* -- measurement ----------------------------------------------------------------
  * With profiling on, every kernel launch of the next call is bracketed by HIP

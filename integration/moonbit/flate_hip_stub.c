@@ -36,3 +36,13 @@ int flate_hip_mbt_deflate_spliced(flate_hip_ctx *c, const uint8_t *in, const uin
                                   uint32_t flags) {
   return flate_hip_deflate_fast_spliced(c, in, in_off, n, out, out_cap, out_len, bit_off, flags);
 }
+
+/* -- exchange step (multi-GPU): the communicator constructor returns its pointer instead of
+ * writing it through a pointer-to-pointer; the gather calls bind include/flate_hip.h directly. -- */
+flate_hip_comm *flate_hip_mbt_comm_new(flate_hip_ctx *c, const uint8_t *unique_id, int rank, int world) {
+  flate_hip_comm *cm = 0;
+  if (flate_hip_comm_init(c, unique_id, rank, world, &cm) != FLATE_HIP_OK) return 0;
+  return cm;
+}
+
+int flate_hip_mbt_comm_is_null(const flate_hip_comm *cm) { return cm == 0; }

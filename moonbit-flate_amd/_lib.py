@@ -14,6 +14,9 @@ EXPORTS = [
     "flate_hip_lz77_matches", "flate_hip_inflate_batch", "flate_hip_deflate_fast_spliced",
     "flate_hip_inflate_spliced", "flate_hip_set_profiling", "flate_hip_last_resident_share",
     "flate_hip_last_timing", "flate_hip_stage_name", "flate_hip_synth_fill", "flate_hip_build_id",
+    "flate_hip_comm_unique_id", "flate_hip_comm_init", "flate_hip_comm_wrap", "flate_hip_comm_destroy",
+    "flate_hip_comm_plan", "flate_hip_comm_set_plan", "flate_hip_gather_layout",
+    "flate_hip_gather_compressed", "flate_hip_gather_begin", "flate_hip_gather_end",
 ]
 
 _lib = None
@@ -71,5 +74,17 @@ def load():
     L.flate_hip_synth_fill.restype = C.c_int
     L.flate_hip_build_id.argtypes = []
     L.flate_hip_build_id.restype = C.c_char_p
+    L.flate_hip_comm_unique_id.argtypes = [vp]
+    L.flate_hip_comm_init.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
+    L.flate_hip_comm_wrap.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
+    L.flate_hip_comm_destroy.argtypes = [vp]
+    L.flate_hip_comm_destroy.restype = None
+    L.flate_hip_comm_plan.argtypes = [vp, u64p, C.POINTER(C.c_uint32)]
+    L.flate_hip_comm_set_plan.argtypes = [vp, C.c_uint64, C.c_uint32]
+    L.flate_hip_gather_layout.argtypes = [C.c_uint32, vp, C.c_uint64, C.c_uint32, u64p, vp, u64p]
+    L.flate_hip_gather_compressed.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, vp, C.c_uint64,
+                                              vp, vp, C.c_uint64, u64p, C.c_uint32]
+    L.flate_hip_gather_begin.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, vp, C.c_uint64]
+    L.flate_hip_gather_end.argtypes = [vp, vp, vp, C.c_uint64, u64p]
     _lib = L
     return L

@@ -10,7 +10,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libflate_hip.so")
 
 SOURCES = ["lz77_kernels.hip",  "huff_pack_kernels.hip", "compact_kernels.hip",
-           "inflate_kernels.hip", "splice_kernels.hip", "flate_api.hip", "synth.cpp"]
+           "inflate_kernels.hip", "splice_kernels.hip", "flate_api.hip", "gather.hip", "synth.cpp"]
 HEADERS = ["flate_common.h", "flate_kernels.h", "lz77_device.h", os.path.join(ROOT, "include", "flate_hip.h")]
 
 
@@ -46,7 +46,7 @@ def build(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
            "-DFLATE_HIP_BUILD_ID=\"%s\"" % source_hash(),
-           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + srcs + ["-o", LIB_PATH, "-lpthread"]
+           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + srcs + ["-o", LIB_PATH, "-lpthread", "-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -93,6 +93,12 @@ struct flate_hip_ctx {
   hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
 };
 
+namespace flate {
+hipStream_t ctx_stream(flate_hip_ctx *c) { return c->stream; }
+int ctx_device(flate_hip_ctx *c) { return c->device; }
+void ctx_set_error(flate_hip_ctx *c, const std::string &msg) { c->hip_err = msg; }
+}  // namespace flate
+
 namespace {
 
 #define HIP_TRY(ctx, expr)                                                         \
@@ -383,6 +389,7 @@ const char *flate_hip_strerror(int code) {
     case FLATE_HIP_E_TOO_LARGE: return "stream too large";
     case FLATE_HIP_E_UNEXPECTED_EOF: return "unexpected EOF";
     case FLATE_HIP_E_INTERNAL: return "internal error: encoder self-check failed";
+    case FLATE_HIP_E_AGAIN: return "a shard outgrew the agreed pad: repeat this batch with the blocking exchange";
     default: return "unknown error";
   }
 }

@@ -144,3 +144,12 @@ __global__ void splice_zero_kernel(SpliceParams P, uint8_t *out);
 size_t inflate_simt_lds_bytes(int lanes_per_wave);  // dynamic LDS of that launch
 
 }  // namespace flate
+
+// the ctx as the other host-side files of the library see it (gather.hip)
+#include <string>
+struct flate_hip_ctx;
+namespace flate {
+hipStream_t ctx_stream(flate_hip_ctx *c);
+int ctx_device(flate_hip_ctx *c);
+void ctx_set_error(flate_hip_ctx *c, const std::string &msg);
+}  // namespace flate

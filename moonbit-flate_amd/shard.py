@@ -162,3 +162,124 @@ def gather_compressed(dist, local_buf, local_off, buf=None, plan=None, pad_to=1 
             return gather_compressed(dist, local_buf, local_off, buf=None, plan=plan, pad_to=pad_to,
                                      wait=True, mode=mode)
     return g
+
+
+# ------------------------------------------------------------------------------------------------
+# The same exchange through the C ABI (include/flate_hip.h: flate_hip_comm_*, flate_hip_gather_*):
+# what a host in the reference's language calls.  The library owns the RCCL communicator and the
+# exchange's HIP stream; this class only marshals buffers.  (The torch.distributed form above stays
+# for the CPU rehearsal with gloo, where there is no RCCL.)
+# ------------------------------------------------------------------------------------------------
+MODES = {"allgather": 0, "sendrecv": 1}
+E_AGAIN = -9
+
+
+def gather_layout(rank_bytes, mode="allgather", pad_to=1 << 20):
+    """(pad, rank_base[], out_bytes) as flate_hip_gather_layout computes them (host arithmetic)."""
+    import ctypes as C
+    from . import _lib
+    L = _lib.load()
+    rb = np.ascontiguousarray(rank_bytes, dtype=np.uint64)
+    base = np.zeros(rb.size, dtype=np.uint64)
+    pad, need = C.c_uint64(0), C.c_uint64(0)
+    rc = L.flate_hip_gather_layout(rb.size, rb.ctypes.data, int(pad_to), MODES[mode], C.byref(pad),
+                                   base.ctypes.data, C.byref(need))
+    if rc != 0:
+        raise ValueError("flate_hip_gather_layout: %d" % rc)
+    return int(pad.value), base, int(need.value)
+
+
+class NativeGathered:
+    """Result of a C-ABI exchange: global stream j (rank-major) = buf[off[j] : off[j] + length[j]]."""
+
+    def __init__(self, buf, off, length, pad):
+        self.buf, self.off, self.length, self.pad = buf, off, length, pad
+
+    def stream(self, j):
+        o = int(self.off[j])
+        return self.buf[o:o + int(self.length[j])]
+
+
+class NativeComm:
+    """One flate_hip_comm: an RCCL communicator created by the library from a unique id that rank 0
+    makes and `dist` (any torch.distributed backend; None for a one-rank communicator) broadcasts."""
+
+    def __init__(self, eng, rank=0, world=1, dist=None):
+        import ctypes as C
+        from . import _lib
+        self._L, self._eng, self.rank, self.world = _lib.load(), eng, int(rank), int(world)
+        uid = np.zeros(128, dtype=np.uint8)
+        if rank == 0:
+            eng._check(self._L.flate_hip_comm_unique_id(uid.ctypes.data))
+        if dist is not None and world > 1:
+            import torch
+            t = torch.from_numpy(uid)
+            if dist.get_backend() == "nccl":
+                t = t.cuda()
+            dist.broadcast(t, src=0)
+            uid = t.cpu().numpy()
+        self._comm = C.c_void_p()
+        eng._check(self._L.flate_hip_comm_init(eng._ctx, uid.ctypes.data, self.rank, self.world,
+                                               C.byref(self._comm)))
+
+    def close(self):
+        if self._comm:
+            self._L.flate_hip_comm_destroy(self._comm)
+            self._comm = None
+
+    def plan(self):
+        import ctypes as C
+        pad, kmax = C.c_uint64(0), C.c_uint32(0)
+        self._L.flate_hip_comm_plan(self._comm, C.byref(pad), C.byref(kmax))
+        return int(pad.value), int(kmax.value)
+
+    def set_plan(self, pad, max_streams):
+        self._eng._check(self._L.flate_hip_comm_set_plan(self._comm, int(pad), int(max_streams)))
+
+    def _out(self, local_buf, need, out):
+        import torch
+        if out is None or out.numel() < need:
+            out = torch.empty(max(need, 16), dtype=torch.uint8, device=local_buf.device)
+        return out
+
+    def gather(self, local_buf, local_off, out=None, mode="allgather", total_streams_cap=None):
+        """Blocking exchange (flate_hip_gather_compressed)."""
+        import ctypes as C
+        local_off = np.ascontiguousarray(local_off, dtype=np.uint64)
+        k = local_off.size - 1
+        cap = int(total_streams_cap or max(k, 1) * self.world * 2 + 16)
+        # room for the padded form whatever the peers hold: the caller's buffer or world x bound
+        need = (int(local_buf.numel()) + (1 << 20)) * self.world
+        out = self._out(local_buf, need, out)
+        off, length = np.zeros(cap, np.uint64), np.zeros(cap, np.uint64)
+        total = C.c_uint64(0)
+        self._eng._check(self._L.flate_hip_gather_compressed(
+            self._comm, local_buf.data_ptr(), local_buf.numel(), local_off.ctypes.data, k,
+            out.data_ptr(), out.numel(), off.ctypes.data, length.ctypes.data, cap, C.byref(total),
+            MODES[mode]))
+        t = int(total.value)
+        return NativeGathered(out, off[:t], length[:t], self.plan()[0])
+
+    def begin(self, local_buf, local_off, out):
+        """Overlapped exchange, padded form (flate_hip_gather_begin): returns at once."""
+        local_off = np.ascontiguousarray(local_off, dtype=np.uint64)
+        self._keep = (local_buf, local_off, out)
+        self._eng._check(self._L.flate_hip_gather_begin(
+            self._comm, local_buf.data_ptr(), local_buf.numel(), local_off.ctypes.data,
+            local_off.size - 1, out.data_ptr(), out.numel()))
+
+    def end(self, total_streams_cap):
+        """Waits for the exchange begun last; returns NativeGathered, or None if a shard outgrew the
+        pad (FLATE_HIP_E_AGAIN: the plan has been raised, repeat the batch with gather())."""
+        import ctypes as C
+        cap = int(total_streams_cap)
+        off, length = np.zeros(cap, np.uint64), np.zeros(cap, np.uint64)
+        total = C.c_uint64(0)
+        rc = self._L.flate_hip_gather_end(self._comm, off.ctypes.data, length.ctypes.data, cap, C.byref(total))
+        out = self._keep[2]
+        self._keep = None
+        if rc == E_AGAIN:
+            return None
+        self._eng._check(rc)
+        t = int(total.value)
+        return NativeGathered(out, off[:t], length[:t], self.plan()[0])

@@ -97,7 +97,8 @@ def test_moonbit_stub_compiles_and_links_against_the_library(lib, tmp_path):
     import ctypes
     stub = ctypes.CDLL(str(so))
     for name in ("flate_hip_mbt_ctx_new", "flate_hip_mbt_ctx_is_null", "flate_hip_mbt_deflate_batch",
-                 "flate_hip_mbt_inflate_batch", "flate_hip_mbt_deflate_spliced"):
+                 "flate_hip_mbt_inflate_batch", "flate_hip_mbt_deflate_spliced",
+                 "flate_hip_mbt_comm_new", "flate_hip_mbt_comm_is_null"):
         assert hasattr(stub, name)
     # every symbol the .mbt binding names in an `extern "C" fn ... = "sym"` exists in the stub or
     # in the library, and the binding never copies a buffer on its way to C
