@@ -53,6 +53,12 @@ typedef struct flate_hip_ctx flate_hip_ctx;
                                       (huffman-bit-writer.mbt:527,780); default is the
                                       reference's own (MoonBit) behaviour                */
 #define FLATE_HIP_LZ_SERIAL 0x4u   /* debug: single-lane match finder kernel            */
+#define FLATE_HIP_SIZE_ONLY 0x8u   /* flate_hip_inflate_batch: decode without storing -- out may be
+                                      NULL and out_off is ignored (no capacity limit); out_len[i] =
+                                      the bytes stream i inflates to (up to its error, if any),
+                                      status / err_off as in a real pass.  What a Reader of a
+                                      stream of unknown size runs first, instead of guessing a
+                                      capacity and retrying                                    */
 
 /* -- lifecycle ------------------------------------------------------------------
  * replaces: Writer::new (writer.mbt:10) / Compressor::new (deflate.mbt:81) state
@@ -108,6 +114,27 @@ int flate_hip_deflate_fast_batch(flate_hip_ctx *ctx, const uint8_t *in,
                                  const uint64_t *in_off, uint32_t n_streams,
                                  uint8_t *out, uint64_t out_cap, uint64_t *out_off,
                                  uint32_t flags);
+
+/* ONE stream written in pieces -- Writer::write as the reference behaves: compressed bytes leave
+ * while later input is still to come (Compressor::write -> fill_store / enc_speed per full
+ * 65535-byte window, deflate.mbt:280-294,222-229,236-277; the sink sees output every >= 240
+ * bytes, huffman-bit-writer.mbt:193-196) instead of everything at close.  The concatenation of
+ * the pieces' output is, bit for bit, what flate_hip_deflate_fast_batch produces for the whole
+ * stream (= Writer::new; write(all); close()).  Between two pieces the stream's DeflateFast state
+ * (hash table, position; deflate-fast.mbt:104-117,156) rests on the device together with the last
+ * 32 KiB of input (max_match_offset) and the bits of the last incomplete output byte.
+ *   n: a multiple of 65535 (whole windows) unless final; final != 0: any n (also 0), ends the
+ *   stream with Writer::close's block (deflate.mbt:171-176).  in / out are HOST buffers;
+ *   out_cap >= flate_hip_stream_bound(n).  Errors are sticky (Compressor.err, deflate.mbt:74):
+ *   after a failed or a final write every further write fails.  One wavefront compresses one
+ *   stream: this is the reference's semantics for a long stream, not the engine's fast path
+ *   (batches of streams are). */
+typedef struct flate_hip_stream flate_hip_stream;
+int flate_hip_stream_open(flate_hip_ctx *ctx, uint32_t flags, flate_hip_stream **stream);
+size_t flate_hip_stream_bound(size_t n);
+int flate_hip_stream_write(flate_hip_stream *stream, const uint8_t *in, uint64_t n, int final,
+                           uint8_t *out, uint64_t out_cap, uint64_t *out_len);
+void flate_hip_stream_free(flate_hip_stream *stream);
 
 /* Match-finder only (replaces DeflateFast::encode, deflate-fast.mbt:123-270), for
  * token-stream parity tests.  A stream is cut into LZ77 chunks exactly as

@@ -46,3 +46,17 @@ flate_hip_comm *flate_hip_mbt_comm_new(flate_hip_ctx *c, const uint8_t *unique_i
 }
 
 int flate_hip_mbt_comm_is_null(const flate_hip_comm *cm) { return cm == 0; }
+
+/* -- one long stream written in pieces; the size-only inflate pass -- */
+flate_hip_stream *flate_hip_mbt_stream_new(flate_hip_ctx *c, uint32_t flags) {
+  flate_hip_stream *st = 0;
+  if (flate_hip_stream_open(c, flags, &st) != FLATE_HIP_OK) return 0;
+  return st;
+}
+
+int flate_hip_mbt_stream_is_null(const flate_hip_stream *st) { return st == 0; }
+
+int flate_hip_mbt_inflate_sizes(flate_hip_ctx *c, const uint8_t *in, const uint64_t *in_off, uint32_t n,
+                                uint64_t *out_len, int32_t *status, int64_t *err_off) {
+  return flate_hip_inflate_batch(c, in, in_off, n, 0, 0, out_len, status, err_off, FLATE_HIP_SIZE_ONLY);
+}

@@ -3,7 +3,7 @@ gmlewis/moonbit-flate (LZ77 match finder -> dynamic-Huffman bit writer, batch in
 
 The hyphen in the directory name means: importlib.import_module("moonbit-flate_amd").
 """
-from .engine import (FlateEngine, FlateError, build_id, deflate_bound, synth, uniform_offsets, lz_chunks,
+from .engine import (FlateEngine, FlateError, StreamWriter, build_id, deflate_bound, synth, uniform_offsets, lz_chunks,
                      tokens_from_matches, SYNTH_KINDS, SEED_TEXT, SEED_RAND, STAGES)
 from . import build as _build
 

@@ -17,6 +17,7 @@ EXPORTS = [
     "flate_hip_comm_unique_id", "flate_hip_comm_init", "flate_hip_comm_wrap", "flate_hip_comm_destroy",
     "flate_hip_comm_plan", "flate_hip_comm_set_plan", "flate_hip_gather_layout",
     "flate_hip_gather_compressed", "flate_hip_gather_begin", "flate_hip_gather_end",
+    "flate_hip_stream_open", "flate_hip_stream_bound", "flate_hip_stream_write", "flate_hip_stream_free",
 ]
 
 _lib = None
@@ -86,5 +87,11 @@ def load():
                                               vp, vp, C.c_uint64, u64p, C.c_uint32]
     L.flate_hip_gather_begin.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, vp, C.c_uint64]
     L.flate_hip_gather_end.argtypes = [vp, vp, vp, C.c_uint64, u64p]
+    L.flate_hip_stream_open.argtypes = [vp, C.c_uint32, C.POINTER(vp)]
+    L.flate_hip_stream_bound.argtypes = [C.c_size_t]
+    L.flate_hip_stream_bound.restype = C.c_size_t
+    L.flate_hip_stream_write.argtypes = [vp, vp, C.c_uint64, C.c_int, vp, C.c_uint64, u64p]
+    L.flate_hip_stream_free.argtypes = [vp]
+    L.flate_hip_stream_free.restype = None
     _lib = L
     return L

@@ -965,6 +965,184 @@ int flate_hip_deflate_fast_spliced(flate_hip_ctx *c, const uint8_t *in, const ui
   return deflate_common(c, in, in_off, n, out, out_cap, bit_off, flags, true, out_len);
 }
 
+// ---- one long stream, written in pieces (Writer::write as the reference behaves: output leaves
+// ---- while later input is still to come, deflate.mbt:280-294) ---------------------------------
+}  // extern "C"
+
+struct flate_hip_stream {
+  flate_hip_ctx *ctx = nullptr;
+  uint32_t flags = 0;
+  DevBuf table, clock, hist, stage, io, out;  // io: {lz77 in_off[2], huff in_off[2]} (u64) + chunk/blk bases
+  uint64_t abs = 0;        // bytes of the stream consumed so far (a multiple of 65535 until the end)
+  uint32_t carry_bits = 0; // bits of the last, incomplete output byte (0..7) ...
+  uint8_t carry = 0;       // ... and their value
+  bool closed = false;
+  int err = 0;             // sticky (Compressor.err, deflate.mbt:74)
+};
+
+namespace {
+constexpr uint64_t kHist = 32768;  // max_match_offset: what a later window can still reference
+
+int stream_write_impl(flate_hip_stream *st, const uint8_t *in, uint64_t n, bool final, uint8_t *out,
+                      uint64_t out_cap, uint64_t *out_len) {
+  flate_hip_ctx *c = st->ctx;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint64_t W0 = st->abs;
+  if (W0 + n >= 0x7ffe0000ull) return FLATE_HIP_E_TOO_LARGE;
+  const uint64_t full = n / kMaxStoreBlockSize, r = n % kMaxStoreBlockSize;
+  const uint32_t nch = (uint32_t)(full + (r >= (uint64_t)kSmallLzMin ? 1 : 0));
+  const uint32_t nblk = (uint32_t)(full + (r > 0 ? 1 : 0));
+  const uint32_t win0 = (uint32_t)(W0 / kMaxStoreBlockSize);
+  int rc;
+  // device staging: [the last 32 KiB of what came before][the new bytes]
+  if ((rc = ensure(c, st->table, kTableSize * 2 + 64))) return rc;
+  if ((rc = ensure(c, st->clock, 64))) return rc;
+  if ((rc = ensure(c, st->hist, kHist + 64))) return rc;
+  if ((rc = ensure(c, st->stage, kHist + n + 64))) return rc;
+  if ((rc = ensure(c, st->io, 256))) return rc;
+  const uint64_t cap_need = flate_hip_deflate_bound(n) + 16;
+  if ((rc = ensure(c, st->out, cap_need + 16))) return rc;
+  uint8_t *stage = (uint8_t *)st->stage.p;
+  if (W0) HIP_TRY(c, hipMemcpyAsync(stage, st->hist.p, kHist, hipMemcpyDeviceToDevice, c->stream));
+  if (n) HIP_TRY(c, hipMemcpyAsync(stage + kHist, in, n, hipMemcpyHostToDevice, c->stream));
+  // index arrays: the match finder sees the stream through a virtual base (absolute positions, the
+  // table's mod-2^16 arithmetic needs them), the entropy stage sees the new bytes only
+  uint64_t h_io[8] = {0, W0 + n, 0, n, 0, 0, 0, 0};
+  uint32_t *h32 = reinterpret_cast<uint32_t *>(h_io + 4);
+  h32[0] = 0; h32[1] = nch;   // chunk_base
+  h32[2] = 0; h32[3] = nblk;  // blk_base
+  HIP_TRY(c, hipMemcpyAsync(st->io.p, h_io, sizeof h_io, hipMemcpyHostToDevice, c->stream));
+  const uint64_t *d_off_abs = (const uint64_t *)st->io.p, *d_off_loc = d_off_abs + 2;
+  const uint32_t *d_chunk_base = (const uint32_t *)((const uint64_t *)st->io.p + 4), *d_blk_base = d_chunk_base + 2;
+  if ((rc = ensure(c, c->d_matches, (size_t)(nch ? nch : 1) * kMatchCapPerChunk * sizeof(uint2) + 16))) return rc;
+  if ((rc = ensure(c, c->d_nmatch, (size_t)nch * 4 + 4))) return rc;
+  if ((rc = ensure(c, c->d_ntok, (size_t)nch * 4 + 4))) return rc;
+  HIP_TRY(c, hipMemsetAsync(c->d_status.p, 0, 4, c->stream));
+  if (nch) {
+    LzParams P{};
+    P.in = stage + kHist - W0;  // virtual: only positions >= W0 - 32768 are ever dereferenced
+    P.in_off = d_off_abs;
+    P.chunk_base = d_chunk_base;
+    P.scan_off = (const uint16_t *)c->scan_tab.p;
+    P.scan_len = c->scan_len;
+    P.matches = (uint2 *)c->d_matches.p;
+    P.chunk_nmatch = (uint32_t *)c->d_nmatch.p;
+    P.chunk_ntok = (uint32_t *)c->d_ntok.p;
+    P.compat_go = (st->flags & FLATE_HIP_COMPAT_GO) ? 1u : 0u;
+    P.status = (int *)c->d_status.p;
+    P.spin_limit = c->spin_limit;
+    P.win0 = win0;
+    hipLaunchKernelGGL(lz77_resume_kernel, dim3(1), dim3(64), 0, c->stream, P, (uint16_t *)st->table.p,
+                       (uint32_t *)st->clock.p, nch);
+  }
+  const size_t nb = (size_t)nblk + 1;
+  if ((rc = ensure(c, c->d_blk_hist, nb * 320 * 4))) return rc;
+  if ((rc = ensure(c, c->d_blk_cl, nb * 320 * 4))) return rc;
+  if ((rc = ensure(c, c->d_blk_hdr, nb * 704 * 4))) return rc;
+  if ((rc = ensure(c, c->d_blk_meta, nb * 16))) return rc;
+  if ((rc = ensure(c, c->d_tile_meta, ((n >> 8) + nb + 2) * 64))) return rc;
+  if ((rc = ensure(c, c->d_out_len, 4 * 8))) return rc;
+  if ((rc = ensure(c, c->d_out_off, 4 * 8))) return rc;
+  if ((rc = ensure(c, c->d_slot_off, 4 * 16))) return rc;
+  uint8_t *d_out = (uint8_t *)st->out.p;
+  HuffParams H{};
+  H.in = stage + kHist;
+  H.in_off = d_off_loc;
+  H.chunk_base = d_chunk_base;
+  H.blk_base = d_blk_base;
+  H.matches = (const uint2 *)c->d_matches.p;
+  H.chunk_nmatch = (const uint32_t *)c->d_nmatch.p;
+  H.chunk_ntok = (const uint32_t *)c->d_ntok.p;
+  H.blk_hist = (uint32_t *)c->d_blk_hist.p;
+  H.blk_cl = (uint32_t *)c->d_blk_cl.p;
+  H.blk_hdr = (uint32_t *)c->d_blk_hdr.p;
+  H.blk_meta = (uint4 *)c->d_blk_meta.p;
+  H.tile_meta = (uint8_t *)c->d_tile_meta.p;
+  H.spliced = 1u;
+  H.stream_sum = (uint64_t *)c->d_slot_off.p;
+  H.stream_bit = (const uint64_t *)c->d_out_off.p;
+  H.out_len = (uint64_t *)c->d_out_len.p;
+  H.out_off = (const uint64_t *)c->d_out_off.p;
+  H.out = d_out;
+  H.status = (int *)c->d_status.p;
+  H.n_streams = 1;
+  H.compat_go = (st->flags & FLATE_HIP_COMPAT_GO) ? 1u : 0u;
+  H.no_close = final ? 0u : 1u;
+  SpliceParams S{};
+  S.sum = (const uint64_t *)c->d_slot_off.p;
+  S.stream_bit = (uint64_t *)c->d_out_off.p;
+  S.total_bytes = (uint64_t *)c->d_out_len.p + 1;
+  S.out_cap = cap_need;
+  S.status = (int *)c->d_status.p;
+  S.n_streams = 1;
+  S.start_bit = st->carry_bits;
+  S.no_close = H.no_close;
+  hipLaunchKernelGGL(huff_hist_kernel, dim3(1), dim3(64), 0, c->stream, H);
+  hipLaunchKernelGGL(huff_code_kernel, dim3(1), dim3(64), 0, c->stream, H);
+  hipLaunchKernelGGL(splice_scan_kernel, dim3(1), dim3(1024), 0, c->stream, S);
+  hipLaunchKernelGGL(splice_zero_kernel, dim3(1), dim3(256), 0, c->stream, S, d_out);
+  // the bits left over from the previous piece share the first byte with this piece's first block
+  if (st->carry_bits) HIP_TRY(c, hipMemcpyAsync(d_out, &st->carry, 1, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(huff_pack_kernel, dim3(1), dim3(64), 0, c->stream, H);
+  HIP_TRY(c, hipGetLastError());
+  uint64_t h_pos[2] = {0, 0};  // {end bit of the piece, total bytes}
+  HIP_TRY(c, hipMemcpyAsync(&h_pos[0], (uint64_t *)c->d_out_off.p + 1, 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(&h_pos[1], (uint64_t *)c->d_out_len.p + 1, 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(&c->h_status_word, c->d_status.p, 4, hipMemcpyDeviceToHost, c->stream));
+  if (!final && n >= kHist)  // what the next piece may still reference
+    HIP_TRY(c, hipMemcpyAsync(st->hist.p, stage + n, kHist, hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->h_status_word) return c->h_status_word <= kStatusUqTimeout ? FLATE_HIP_E_INTERNAL : c->h_status_word;
+  const uint64_t whole = final ? h_pos[1] : (h_pos[0] >> 3);
+  if (whole > out_cap) return FLATE_HIP_E_OUT_TOO_SMALL;
+  if (whole) HIP_TRY(c, hipMemcpyAsync(out, d_out, whole, hipMemcpyDeviceToHost, c->stream));
+  st->carry_bits = final ? 0u : (uint32_t)(h_pos[0] & 7u);
+  if (st->carry_bits) HIP_TRY(c, hipMemcpyAsync(&st->carry, d_out + whole, 1, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (st->carry_bits) st->carry &= (uint8_t)((1u << st->carry_bits) - 1u);
+  st->abs = W0 + n;
+  *out_len = whole;
+  return FLATE_HIP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int flate_hip_stream_open(flate_hip_ctx *c, uint32_t flags, flate_hip_stream **out) {
+  if (!c || !out || (flags & ~FLATE_HIP_COMPAT_GO)) return FLATE_HIP_E_INVALID;
+  flate_hip_stream *st = new flate_hip_stream();
+  st->ctx = c;
+  st->flags = flags;
+  *out = st;
+  return FLATE_HIP_OK;
+}
+
+void flate_hip_stream_free(flate_hip_stream *st) {
+  if (!st) return;
+  (void)hipSetDevice(st->ctx->device);
+  for (DevBuf *b : {&st->table, &st->clock, &st->hist, &st->stage, &st->io, &st->out}) release(*b);
+  delete st;
+}
+
+size_t flate_hip_stream_bound(size_t n) { return flate_hip_deflate_bound(n) + 8; }
+
+int flate_hip_stream_write(flate_hip_stream *st, const uint8_t *in, uint64_t n, int final, uint8_t *out,
+                           uint64_t out_cap, uint64_t *out_len) {
+  if (!st || !out_len || (n && !in) || !out) return FLATE_HIP_E_INVALID;
+  *out_len = 0;
+  if (st->err) return st->err;
+  if (st->closed) return FLATE_HIP_E_INVALID;
+  // a piece that is not the last one is whole windows: the 65535-byte staging window of
+  // Compressor::fill_store (deflate.mbt:222-229) is what enc_speed compresses at a time
+  if (!final && (n == 0 || n % kMaxStoreBlockSize != 0)) return FLATE_HIP_E_INVALID;
+  st->ctx->hip_err.clear();
+  const int rc = stream_write_impl(st, in, n, final != 0, out, out_cap, out_len);
+  if (rc != FLATE_HIP_OK && rc != FLATE_HIP_E_OUT_TOO_SMALL) st->err = rc;  // sticky, as Compressor.err
+  if (rc == FLATE_HIP_E_OUT_TOO_SMALL) st->err = rc;  // (the piece's state is gone with the call)
+  if (rc == FLATE_HIP_OK && final) st->closed = true;
+  return rc;
+}
+
 int flate_hip_lz77_matches(flate_hip_ctx *c, const uint8_t *in, const uint64_t *in_off, uint32_t n,
                            uint32_t flags, uint32_t *n_chunks, uint64_t *n_recs_cap,
                            uint32_t *chunk_nmatch, uint64_t *chunk_rec_off, uint32_t *recs) {
@@ -1019,12 +1197,18 @@ static int inflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
                           uint8_t *out, const uint64_t *out_off, uint64_t *out_len, int32_t *status,
                           int64_t *err_off, uint32_t flags, uint64_t spliced_len) {
   const bool spliced = spliced_len != 0;
+  const bool size_only = (flags & FLATE_HIP_SIZE_ONLY) != 0 && !spliced;
   const uint64_t in_bytes = spliced ? spliced_len : in_off[n];
   HIP_TRY(c, hipSetDevice(c->device));
   const bool dev = (flags & FLATE_HIP_DEVICE_PTRS) != 0;
   int rc;
   const uint8_t *d_in = in;
   uint8_t *d_out = out;
+  std::vector<uint64_t> no_slots;
+  if (size_only) {  // nothing is stored: no output buffer, no slots
+    no_slots.assign((size_t)n + 1, 0);
+    out_off = no_slots.data();
+  }
   if (!dev) {
     if ((rc = ensure(c, c->d_in, in_bytes + 16))) return rc;
     if ((rc = ensure(c, c->d_out, out_off[n] + 16))) return rc;
@@ -1050,12 +1234,15 @@ static int inflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
   I.n_streams = n;
   I.bit_off = spliced ? (const uint64_t *)c->d_in_off.p : nullptr;
   I.in_len = in_bytes;
+  I.size_only = size_only ? 1u : 0u;
   {
     StageTimer t(c, FLATE_HIP_STAGE_INFLATE);
     // large batches: one lane per stream (64 streams per wavefront); small ones: one wavefront
     // per stream
     // (its bit positions are 32-bit: every compressed stream must be < 256 MiB)
-    bool simt = spliced || n >= c->inflate_simt_min;
+    // (size-only passes use the wave-per-stream decoder: its history is the LDS window, the
+    // lane-per-stream one reads its history back from the output it has written)
+    bool simt = (spliced || n >= c->inflate_simt_min) && !size_only;
     for (uint32_t i = 0; i < n && simt && !spliced; ++i) simt = in_off[i + 1] - in_off[i] < (1ull << 28);
     if (simt) {
       // streams per wavefront: as many as still leave four wavefronts (one per SIMD) per CU
@@ -1075,7 +1262,7 @@ static int inflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
   HIP_TRY(c, hipMemcpyAsync(out_len, c->d_out_len.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(status, c->d_istatus.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(err_off, c->d_ierr.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
-  if (!dev)
+  if (!dev && !size_only)
     HIP_TRY(c, hipMemcpyAsync(out, c->d_out.p, out_off[n], hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   const bool used[FLATE_HIP_STAGE_COUNT] = {false, false, false, true};
@@ -1148,12 +1335,16 @@ extern "C" {
 int flate_hip_inflate_batch(flate_hip_ctx *c, const uint8_t *in, const uint64_t *in_off, uint32_t n,
                             uint8_t *out, const uint64_t *out_off, uint64_t *out_len,
                             int32_t *status, int64_t *err_off, uint32_t flags) {
-  if (!c || !in_off || !out_off || !out_len || !status || !err_off || (n && (!in || !out)))
+  const bool size_only = (flags & FLATE_HIP_SIZE_ONLY) != 0;
+  if (!c || !in_off || !out_len || !status || !err_off || (n && !in) ||
+      (!size_only && (!out_off || (n && !out))))
     return FLATE_HIP_E_INVALID;
   c->hip_err.clear();
   if (n == 0) return FLATE_HIP_OK;
   for (uint32_t i = 0; i < n; ++i)
-    if (in_off[i + 1] < in_off[i] || out_off[i + 1] < out_off[i]) return FLATE_HIP_E_INVALID;
+    if (in_off[i + 1] < in_off[i] || (!size_only && out_off[i + 1] < out_off[i])) return FLATE_HIP_E_INVALID;
+  if (size_only)
+    return inflate_common(c, in, in_off, n, nullptr, nullptr, out_len, status, err_off, flags, 0);
   for (uint32_t i = 0; i < n; ++i)
     if (in_off[i + 1] - in_off[i] >= 0x7ffe0000ull) return FLATE_HIP_E_TOO_LARGE;
   // host pointers and a large batch: decode group g while g+1 is copied in and g-1 out

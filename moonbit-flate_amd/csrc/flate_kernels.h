@@ -40,6 +40,10 @@ struct LzParams {
   uint32_t gtable_blocks;  // tables behind `gtables` (a guest block beyond them does nothing)
   uint32_t spin_limit;     // polls before a bounded wait gives up
   uint32_t inject_drop_push;  // test hook (option debug_drop_window_push): drop that hand-over
+  // resumable single-stream launches (flate_hip_stream_write): the stream's first LZ77 window in this
+  // launch has absolute index win0 (in / in_off then describe the stream through a virtual base:
+  // in + absolute position is valid for the 32 KiB of history and the new bytes); 0 otherwise
+  uint32_t win0;
   // measurement aid: the launch counts the streams it took from the queue here (null = off)
   uint32_t *taken;
   // Window-granular scheduling of multi-window streams (persistent MULTI launches): the unit of
@@ -82,6 +86,8 @@ struct HuffParams {
   uint32_t n_streams;
   uint32_t compat_go;
   uint32_t sid0;  // first stream of this launch (sub-batched launches; block b handles sid0 + b)
+  uint32_t no_close;  // spliced mode: the batch's last stream does not write Writer::close's block
+                      // (a stream that continues in a later call: flate_hip_stream_write)
 };
 
 struct CompactParams {
@@ -111,6 +117,7 @@ struct InfParams {
   // NULL: independent streams given by in_off.
   const uint64_t *bit_off;
   uint64_t in_len;
+  uint32_t size_only;  // inflate_kernel: decode and count, store nothing (FLATE_HIP_SIZE_ONLY)
 };
 
 __global__ void lz77_serial_kernel(LzParams P);
@@ -118,6 +125,9 @@ template <bool MULTI>
 __global__ void lz77_wave_kernel(LzParams P);
 template <bool MULTI>
 __global__ void lz77_guest_kernel(LzParams P);
+// one stream continued from an earlier launch: table and sweep clock come from / go back to `table_io`,
+// `clock_io`; runs the nwin windows from P.win0 on
+__global__ void lz77_resume_kernel(LzParams P, uint16_t *table_io, uint32_t *clock_io, uint32_t nwin);
 __global__ void huff_hist_kernel(HuffParams P);
 __global__ void huff_code_kernel(HuffParams P);
 __global__ void huff_pack_kernel(HuffParams P);
@@ -138,6 +148,8 @@ struct SpliceParams {
   uint64_t out_cap;
   int *status;            // -2 if total_bytes > out_cap
   uint32_t n_streams;
+  uint64_t start_bit;     // bit position of the first stream's first block (0; a continued stream: its carry)
+  uint32_t no_close;      // no closing block behind the last stream: total_bytes = ceil(end bit / 8)
 };
 __global__ void splice_scan_kernel(SpliceParams P);
 __global__ void splice_zero_kernel(SpliceParams P, uint8_t *out);

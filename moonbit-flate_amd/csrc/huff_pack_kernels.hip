@@ -895,7 +895,7 @@ __global__ __launch_bounds__(64) void huff_pack_kernel(HuffParams P) {
     const uint64_t mis = (uint64_t)((uintptr_t)P.out & 3u);
     const uint64_t g0 = P.stream_bit[sid] + 8 * mis;  // relative to the aligned dword grid of out
     uint64_t g1 = P.stream_bit[sid + 1] + 8 * mis;
-    const bool last_stream = sid + 1 == P.n_streams;
+    const bool last_stream = sid + 1 == P.n_streams && !P.no_close;
     if (last_stream) g1 = ((g1 + 3 + 7) & ~7ull) + 32;  // + closing block
     out_bits = g1 - g0;
     S.head = 0;
@@ -1008,7 +1008,7 @@ __global__ __launch_bounds__(64) void huff_pack_kernel(HuffParams P) {
     const uint32_t eob = sh.lit_cl[kEndBlockMarker];
     sink_emit(S, eob & 0xffffu, lane == 0 ? (eob >> 16) : 0u, lane);
   }
-  if (!P.spliced || sid + 1 == P.n_streams)
+  if (!P.spliced || (sid + 1 == P.n_streams && !P.no_close))
     emit_stored(S, g.stream, 0, true, lane);  // Compressor::close (deflate.mbt:171-176)
   sink_finish(S, lane);
   // the sizes computed by huff_code_kernel and the bits actually written must agree

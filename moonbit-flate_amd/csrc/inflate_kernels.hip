@@ -218,8 +218,11 @@ __global__ __launch_bounds__(64) void inflate_kernel(InfParams P) {
   const int lane = threadIdx.x;
   const uint32_t sid = blockIdx.x;
   if (sid >= P.n_streams) return;
-  uint8_t *out = P.out + P.out_off[sid];
-  const uint64_t cap64 = P.out_off[sid + 1] - P.out_off[sid];
+  // size_only: the same decoding (the 32 KiB window in LDS is all the history it needs), nothing
+  // stored to HBM and no capacity limit: out_len becomes the size the stream inflates to
+  const bool size_only = P.size_only != 0;
+  uint8_t *out = size_only ? nullptr : P.out + P.out_off[sid];
+  const uint64_t cap64 = size_only ? ~0ull : P.out_off[sid + 1] - P.out_off[sid];
   const uint32_t out_cap = cap64 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)cap64;
   const uint8_t *in = P.in + P.in_off[sid];
   const uint32_t in_len = (uint32_t)(P.in_off[sid + 1] - P.in_off[sid]);
@@ -259,7 +262,8 @@ __global__ __launch_bounds__(64) void inflate_kernel(InfParams P) {
   // read_flush (dict-decoder.mbt:200-209): window -> HBM, coalesced
   auto flush = [&]() {
     __syncthreads();
-    for (uint32_t i = fpos + lane; i < opos; i += 64) out[i] = sh.win[i & (kWin - 1)];
+    if (!size_only)
+      for (uint32_t i = fpos + lane; i < opos; i += 64) out[i] = sh.win[i & (kWin - 1)];
     fpos = opos;
   };
 
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(InfParams P) {
       }
       for (uint32_t i = lane; i < cnt; i += 64) {
         const uint8_t v = in[ip + i];
-        out[opos + i] = v;
+        if (!size_only) out[opos + i] = v;
         sh.win[(opos + i) & (kWin - 1)] = v;
       }
       opos += cnt;

@@ -231,13 +231,15 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
   const uint16_t *scan_tab = P.scan_off;
   uint32_t pf_val = 0, pf_sink = 0;
 
-  const uint32_t c_stop = c_end < g.nchunks ? c_end : g.nchunks;
+  // (w0 != 0 only in resumed launches: the stream's chunks of THIS launch are windows w0, w0+1, ...)
+  const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.win0);
+  const uint32_t c_stop = c_end < w0 + g.nchunks ? c_end : w0 + g.nchunks;
   for (uint32_t c = c_begin; c < c_stop; ++c) {
     const uint32_t W = c * (uint32_t)kMaxStoreBlockSize;
     const uint64_t rem_len = g.len - W;
     const int n = rem_len < (uint64_t)kMaxStoreBlockSize ? (int)rem_len : kMaxStoreBlockSize;
     const uint8_t *src = g.stream + W;
-    uint2 *mout = P.matches + g.mbase + (uint64_t)c * kMatchCapPerChunk;
+    uint2 *mout = P.matches + g.mbase + (uint64_t)(c - w0) * kMatchCapPerChunk;
     uint32_t nm = 0;
     uint32_t acc_len = 0;  // per-lane partial sums of match lengths
     const int s_limit = n - kInputMargin;
@@ -694,11 +696,11 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
     for (int d = 32; d >= 1; d >>= 1) sumlen += __shfl_xor(sumlen, d);
     if (pf_sink == 0x9e3779b9u && P.debug) P.debug[0] = pf_sink;  // keeps the look-ahead loads alive
     if (lane == 0) {
-      P.chunk_nmatch[g.chunk0 + c] = nm;
-      P.chunk_ntok[g.chunk0 + c] = (uint32_t)n - sumlen + nm;
+      P.chunk_nmatch[g.chunk0 + c - w0] = nm;
+      P.chunk_ntok[g.chunk0 + c - w0] = (uint32_t)n - sumlen + nm;
 #ifdef FLATE_LZ_STAMPS
       if (P.debug) {
-        uint64_t *d = P.debug + (uint64_t)(g.chunk0 + c) * 8;
+        uint64_t *d = P.debug + (uint64_t)(g.chunk0 + c - w0) * 8;
         d[0] = st_dup; d[1] = st_load; d[2] = st_ev; d[3] = st_commit; d[4] = st_nb; d[5] = nm;
         d[6] = st_ext; d[7] = st_sparse;
       }
@@ -915,6 +917,31 @@ __global__ __launch_bounds__(64) void lz77_guest_kernel(LzParams P) {
     lz77_stream<MULTI, true>(P, P.stream_ids[q], table, lane, 0, 0xffffffffu, nullptr, tags);
     __syncthreads();
     prev = q;
+  }
+}
+
+// A stream that continues across calls (flate_hip_stream_write): the table and the sweep clock rest
+// in global memory between the calls, exactly as between two window units (uq_run) -- but the next
+// launch is a later kernel on the same HIP stream, so plain loads and stores are enough.
+__global__ __launch_bounds__(64) void lz77_resume_kernel(LzParams P, uint16_t *table_io, uint32_t *clock_io,
+                                                          uint32_t nwin) {
+  __shared__ uint16_t table[kTableSize];
+  const int lane = threadIdx.x;
+  uint32_t clock = 0;
+  if (P.win0 != 0) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(table_io);
+    uint4 *dst = reinterpret_cast<uint4 *>(table);
+    for (int i = lane; i < (int)(kTableSize * sizeof(uint16_t) / 16); i += 64) dst[i] = src[i];
+    clock = *clock_io;
+  }
+  __syncthreads();
+  lz77_stream<true>(P, 0, table, lane, P.win0, P.win0 + nwin, &clock);
+  __syncthreads();
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(table);
+    uint4 *dst = reinterpret_cast<uint4 *>(table_io);
+    for (int i = lane; i < (int)(kTableSize * sizeof(uint16_t) / 16); i += 64) dst[i] = src[i];
+    if (lane == 0) *clock_io = clock;
   }
 }
 

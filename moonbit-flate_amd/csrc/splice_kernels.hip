@@ -61,14 +61,15 @@ __global__ __launch_bounds__(1024) void splice_scan_kernel(SpliceParams P) {
     part[t] = v;
     __syncthreads();
   }
-  uint64_t x = t ? apply(part[t - 1], 0) : 0;  // position in front of this thread's chunk
+  uint64_t x = t ? apply(part[t - 1], P.start_bit) : P.start_bit;  // position in front of this thread's chunk
   for (uint64_t i = lo; i < hi; ++i) {
     P.stream_bit[i] = x;
     x = apply(PosMap{P.sum[2 * i], P.sum[2 * i + 1]}, x);
   }
   if (t == 1023) {
     P.stream_bit[n] = x;
-    const uint64_t bytes = (align8(x + 3) >> 3) + 4;  // closing block: 3 bits, padding, LEN, NLEN
+    // closing block: 3 bits, padding, LEN, NLEN (not behind a stream that continues in a later call)
+    const uint64_t bytes = P.no_close ? (align8(x) >> 3) : (align8(x + 3) >> 3) + 4;
     *P.total_bytes = bytes;
     if (bytes + 3 > P.out_cap) atomicExch(P.status, -2);  // + the rest of the last dword
   }
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void splice_zero_kernel(SpliceParams P, uint8_
       dst[(g >> 5) - 1] = 0;
     }
   }
-  if (i == P.n_streams) {  // closing block: 3 bits, padding, LEN, NLEN -- at most 3 more dwords
+  if (i == P.n_streams && !P.no_close) {  // closing block: 3 bits, padding, LEN, NLEN -- at most 3 more dwords
     const uint64_t end = (*P.total_bytes + mis) * 8;
     for (uint64_t d = (g >> 5) + 1; d * 32 < end; ++d) dst[d] = 0;
   }

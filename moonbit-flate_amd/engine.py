@@ -13,6 +13,7 @@ from . import _lib
 DEVICE_PTRS = 0x1
 COMPAT_GO = 0x2
 LZ_SERIAL = 0x4
+SIZE_ONLY = 0x8
 
 SYNTH_RAMP, SYNTH_TEXT, SYNTH_RAND, SYNTH_ZERO = 0, 1, 2, 3
 SYNTH_KINDS = {"ramp": SYNTH_RAMP, "text": SYNTH_TEXT, "rand": SYNTH_RAND, "zero": SYNTH_ZERO}
@@ -205,6 +206,29 @@ class FlateEngine:
             self._check(rc)
         return out, out_off, out_len, status, err_off
 
+    def inflate_sizes(self, data, in_off):
+        """Decode without storing (FLATE_HIP_SIZE_ONLY): returns (out_len, status, err_off) -- the size
+        every stream inflates to (up to its error, if any).  Host or device input."""
+        in_off = np.ascontiguousarray(in_off, dtype=np.uint64)
+        n = in_off.size - 1
+        out_len = np.zeros(max(n, 1), dtype=np.uint64)
+        status = np.zeros(max(n, 1), dtype=np.int32)
+        err_off = np.full(max(n, 1), -1, dtype=np.int64)
+        device = _is_torch(data)
+        if not device:
+            data = np.ascontiguousarray(data, dtype=np.uint8)
+        in_ptr = data.data_ptr() if device else data.ctypes.data
+        rc = self._L.flate_hip_inflate_batch(self._ctx, in_ptr, in_off.ctypes.data, n, None, None,
+                                             out_len.ctypes.data, status.ctypes.data, err_off.ctypes.data,
+                                             SIZE_ONLY | (DEVICE_PTRS if device else 0))
+        if rc != 0 and rc not in (E_OUT_TOO_SMALL, E_CORRUPT, E_UNEXPECTED_EOF):
+            self._check(rc)
+        return out_len[:n], status[:n], err_off[:n]
+
+    def open_stream(self, compat_go=False):
+        """One stream written in pieces (flate_hip_stream_*): see StreamWriter."""
+        return StreamWriter(self, compat_go)
+
     def deflate_spliced(self, data, in_off, out=None, compat_go=False):
         """Compress the streams as deflate_batch does, but into ONE legal DEFLATE stream that
         inflates to the concatenation of the inputs.
@@ -295,6 +319,50 @@ class FlateEngine:
             r = recs[int(rec_off[c]):int(rec_off[c]) + int(nmatch[c])]
             out.append((r[:, 0].copy(), r[:, 1].copy()))
         return out
+
+
+class StreamWriter:
+    """Writer::write as the reference behaves for ONE long stream: every write() of whole
+    65535-byte windows returns the compressed bytes that are complete so far; close(tail) ends the
+    stream.  The concatenation equals deflate_batch of the whole stream, bit for bit."""
+    WINDOW = MAX_STORE_BLOCK_SIZE
+
+    def __init__(self, eng, compat_go=False):
+        self._eng, self._L = eng, eng._L
+        self._st = C.c_void_p()
+        eng._check(self._L.flate_hip_stream_open(eng._ctx, COMPAT_GO if compat_go else 0, C.byref(self._st)))
+
+    def _write(self, piece, final):
+        piece = np.ascontiguousarray(piece, dtype=np.uint8)
+        cap = int(self._L.flate_hip_stream_bound(piece.size))
+        out = np.empty(cap, dtype=np.uint8)
+        n = C.c_uint64(0)
+        rc = self._L.flate_hip_stream_write(self._st, piece.ctypes.data if piece.size else None, piece.size,
+                                            1 if final else 0, out.ctypes.data, cap, C.byref(n))
+        self._eng._check(rc)
+        return out[:int(n.value)]
+
+    def write(self, piece):
+        """piece: a multiple of 65535 bytes.  Returns the output bytes finished by it."""
+        return self._write(piece, False)
+
+    def close(self, tail=b""):
+        """The rest of the stream (any length) and Writer::close.  Returns the last output bytes."""
+        tail = np.frombuffer(bytes(tail), dtype=np.uint8) if not isinstance(tail, np.ndarray) else tail
+        out = self._write(tail, True)
+        self.free()
+        return out
+
+    def free(self):
+        if self._st:
+            self._L.flate_hip_stream_free(self._st)
+            self._st = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 # status codes of inflate_batch (include/flate_hip.h)

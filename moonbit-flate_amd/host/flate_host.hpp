@@ -5,9 +5,12 @@
 //   writer_closed_error                  deflate.mbt:154
 //   &Reader::new / read / close, ioeof    inflate.mbt:305,382,410,19
 //   corrupt_input_error                   inflate.mbt:38
-// The reference is single-stream and synchronous; the GPU engine is a batch engine, so Writer
-// buffers write() calls (the 65535-byte staging window of deflate.mbt:222-229 makes the output a
-// function of the concatenated bytes only) and compresses in close().  BatchWriter (below) closes
+// The reference is single-stream and synchronous: Compressor::write compresses every full
+// 65535-byte window as soon as it is there and the sink sees the bytes (deflate.mbt:280-294,
+// huffman-bit-writer.mbt:193-196).  Writer does the same through flate_hip_stream_write: write()
+// calls are staged (the output is a function of the concatenated bytes only, deflate.mbt:222-229),
+// and whenever `emit_windows` full windows are pending they are compressed and their finished bytes
+// go to the sink -- memory stays bounded and output leaves before close().  BatchWriter (below) closes
 // many Writers with one kernel pipeline -- the intended way to use the engine -- and a Writer built
 // with chunk_bytes > 0 cuts ONE large stream into independent chunks that the GPU compresses in
 // parallel and splices into one legal DEFLATE stream (different bytes than a single
@@ -110,12 +113,24 @@ inline Err compress_spliced(Engine &e, const std::vector<std::vector<uint8_t>> &
 // parallelism on the GPU, this mode does.
 class Writer {
  public:
-  Writer(ByteSink &w, Engine &e, uint32_t flags = 0, size_t chunk_bytes = 0)
-      : w_(w), e_(e), flags_(flags), chunk_(chunk_bytes) {}
+  static constexpr size_t kWindow = 65535;  // max_store_block_size, deflate-fast.mbt:46
+  // emit_windows: full windows staged before they are compressed and handed to the sink (16 = 1 MiB)
+  Writer(ByteSink &w, Engine &e, uint32_t flags = 0, size_t chunk_bytes = 0, size_t emit_windows = 16)
+      : w_(w), e_(e), flags_(flags), chunk_(chunk_bytes), emit_(emit_windows ? emit_windows : 1) {}
+  ~Writer() { flate_hip_stream_free(st_); }
+  Writer(const Writer &) = delete;
+  Writer &operator=(const Writer &) = delete;
 
   std::pair<int, Err> write(const uint8_t *p, size_t n) {  // deflate.mbt:280-294
     if (err_) return {0, err_};
     pending_.insert(pending_.end(), p, p + n);
+    if (chunk_ == 0 && !batch_member_ && pending_.size() >= emit_ * kWindow) {
+      const size_t k = pending_.size() / kWindow * kWindow;  // every full window that is there
+      if (Err er = feed(k, false)) {
+        err_ = er;
+        return {0, err_};
+      }
+    }
     return {(int)n, std::nullopt};
   }
   std::pair<int, Err> write(const std::vector<uint8_t> &b) { return write(b.data(), b.size()); }
@@ -123,35 +138,54 @@ class Writer {
   Err close() {  // deflate.mbt:157-183
     if (err_ && *err_ == writer_closed_error()) return std::nullopt;
     if (err_) return err_;
-    std::vector<std::vector<uint8_t>> out;
     Err er;
     if (chunk_ > 0 && pending_.size() > chunk_) {
       std::vector<std::vector<uint8_t>> parts;
+      std::vector<uint8_t> one;
       for (size_t o = 0; o < pending_.size(); o += chunk_)
         parts.emplace_back(pending_.begin() + o, pending_.begin() + std::min(pending_.size(), o + chunk_));
-      out.resize(1);
-      er = compress_spliced(e_, parts, out[0], nullptr, flags_);
+      er = compress_spliced(e_, parts, one, nullptr, flags_);
+      if (!er) {
+        auto r = w_.write(one.data(), one.size());
+        er = r.second;
+      }
     } else {
-      er = compress_batch(e_, {pending_}, out, flags_);
+      er = feed(pending_.size(), true);  // the rest (any length) + Writer::close's block
     }
     if (er) {
       err_ = er;
       return err_;
     }
-    auto r = w_.write(out[0].data(), out[0].size());
-    if (r.second) {
-      err_ = r.second;
-      return err_;
-    }
     err_ = writer_closed_error();
     return std::nullopt;
   }
+  // compressed bytes handed to the sink so far (before close(): the pieces already emitted)
+  uint64_t emitted() const { return emitted_; }
 
  private:
+  // compress the first n staged bytes as the stream's next piece and forward what is finished
+  Err feed(size_t n, bool final) {
+    if (!e_.ok()) return make_error(e_, e_.status());
+    if (!st_) {
+      const int rc = flate_hip_stream_open(e_.ctx(), flags_, &st_);
+      if (rc != 0) return make_error(e_, rc);
+    }
+    std::vector<uint8_t> out(flate_hip_stream_bound(n));
+    uint64_t len = 0;
+    const int rc = flate_hip_stream_write(st_, pending_.data(), n, final ? 1 : 0, out.data(), out.size(), &len);
+    if (rc != 0) return make_error(e_, rc);
+    pending_.erase(pending_.begin(), pending_.begin() + n);
+    emitted_ += len;
+    auto r = w_.write(out.data(), len);
+    return r.second;
+  }
   ByteSink &w_;
   Engine &e_;
   uint32_t flags_;
-  size_t chunk_;
+  size_t chunk_, emit_;
+  bool batch_member_ = false;  // closed by a BatchWriter: staged until close_all
+  flate_hip_stream *st_ = nullptr;
+  uint64_t emitted_ = 0;
   std::vector<uint8_t> pending_;
   Err err_;
   friend class BatchWriter;
@@ -166,6 +200,7 @@ class BatchWriter {
   explicit BatchWriter(Engine &e, uint32_t flags = 0) : e_(e), flags_(flags) {}
   Writer &add(ByteSink &sink) {
     ws_.emplace_back(new Writer(sink, e_, flags_));
+    ws_.back()->batch_member_ = true;
     return *ws_.back();
   }
   size_t size() const { return ws_.size(); }
@@ -244,7 +279,27 @@ inline const IOError &err_unexpected_eof() {  // @io.err_unexpected_eof via no_e
 struct Inflated {
   std::vector<uint8_t> bytes;  // what was decoded (also in front of an error, as read() flushes it)
   Err err;                     // nullopt, corrupt_input_error(offset) or err_unexpected_eof
+  int status = 0;              // the FLATE_HIP_E_* code behind err (0 = none)
 };
+
+// The size every stream inflates to, without storing anything (FLATE_HIP_SIZE_ONLY): what a Reader
+// of a stream of unknown size runs first.  sizes[i] counts the bytes in front of an error, too.
+inline Err inflate_sizes(Engine &e, const std::vector<std::vector<uint8_t>> &streams, std::vector<uint64_t> &sizes) {
+  if (!e.ok()) return make_error(e, e.status());
+  const uint32_t n = (uint32_t)streams.size();
+  std::vector<uint64_t> in_off(n + 1, 0);
+  std::vector<int32_t> status(n + 1, 0);
+  std::vector<int64_t> err_off(n + 1, -1);
+  for (uint32_t i = 0; i < n; ++i) in_off[i + 1] = in_off[i] + streams[i].size();
+  std::vector<uint8_t> in(in_off[n] + 8);
+  for (uint32_t i = 0; i < n; ++i) std::copy(streams[i].begin(), streams[i].end(), in.begin() + in_off[i]);
+  sizes.assign(n + 1, 0);
+  const int rc = flate_hip_inflate_batch(e.ctx(), in.data(), in_off.data(), n, nullptr, nullptr, sizes.data(),
+                                         status.data(), err_off.data(), FLATE_HIP_SIZE_ONLY);
+  sizes.resize(n);
+  if (rc != 0 && rc != FLATE_HIP_E_CORRUPT && rc != FLATE_HIP_E_UNEXPECTED_EOF) return make_error(e, rc);
+  return std::nullopt;
+}
 
 // Decode independent streams in one batch.  sizes[i] = capacity for stream i's output.
 inline Err decompress_batch(Engine &e, const std::vector<std::vector<uint8_t>> &streams,
@@ -269,6 +324,7 @@ inline Err decompress_batch(Engine &e, const std::vector<std::vector<uint8_t>> &
   for (uint32_t i = 0; i < n; ++i) {
     out[i].bytes.assign(buf.begin() + out_off[i], buf.begin() + out_off[i] + out_len[i]);
     out[i].err = std::nullopt;
+    out[i].status = status[i];
     if (status[i] == FLATE_HIP_E_CORRUPT) out[i].err = corrupt_input_error(err_off[i]);
     else if (status[i] == FLATE_HIP_E_UNEXPECTED_EOF) out[i].err = err_unexpected_eof();
     else if (status[i] != 0) out[i].err = make_error(e, status[i]);
@@ -295,9 +351,12 @@ struct BytesReader : ByteSource {  // @io.Buffer used as source
 };
 
 // &Reader::new(r) -> Decompressor (inflate.mbt:305) with read (:382-405) and close (:410-415).
-// The engine is a batch engine: the first read() pulls the whole source and decodes it; the
-// bytes and errors then come out as the reference hands them out -- data first, the error
-// (ioeof at a clean end) together with the last bytes, nothing but the error afterwards.
+// The engine is a batch engine: the first read() pulls the whole source and decodes it in ONE pass
+// of known size -- a size-only pass first (FLATE_HIP_SIZE_ONLY: the decoder runs without storing and
+// reports what the stream inflates to), then the decode into exactly that much; no capacity is
+// guessed and nothing is decoded twice into a buffer that turns out too small.  The bytes and
+// errors then come out as the reference hands them out -- data first, the error (ioeof at a clean
+// end) together with the last bytes, nothing but the error afterwards.
 class Reader {
  public:
   Reader(ByteSource &r, Engine &e, uint64_t size_hint = 0) : r_(&r), e_(e), hint_(size_hint) {}
@@ -345,23 +404,28 @@ class Reader {
         break;
       }
     }
-    uint64_t cap = hint_ ? hint_ : std::max<uint64_t>(4096, 8 * src.size());
-    for (;;) {  // the output size is not known in advance: grow the slot until it fits
-      std::vector<Inflated> out;
-      Err er = decompress_batch(e_, {src}, {cap}, out);
-      if (er) {
+    uint64_t cap = hint_;
+    if (cap == 0) {  // unknown size: ask the decoder
+      std::vector<uint64_t> sizes;
+      if (Err er = inflate_sizes(e_, {src}, sizes)) {
         err_ = er;
         return;
       }
-      const bool small = out[0].err && out[0].err->msg.find("too small") != std::string::npos;
-      if (small && cap < (1ull << 31)) {
-        cap *= 4;
-        continue;
-      }
-      data_ = std::move(out[0].bytes);
-      err_ = out[0].err ? out[0].err : Err(ioeof());
+      cap = sizes[0];
+    }
+    std::vector<Inflated> out;
+    Err er = decompress_batch(e_, {src}, {cap}, out);
+    if (!er && out[0].status == FLATE_HIP_E_OUT_TOO_SMALL && hint_ != 0) {  // a wrong hint: the exact size
+      std::vector<uint64_t> sizes;
+      er = inflate_sizes(e_, {src}, sizes);
+      if (!er) er = decompress_batch(e_, {src}, {sizes[0]}, out);
+    }
+    if (er) {
+      err_ = er;
       return;
     }
+    data_ = std::move(out[0].bytes);
+    err_ = out[0].err ? out[0].err : Err(ioeof());
   }
   ByteSource *r_;
   Engine &e_;

@@ -142,5 +142,40 @@ int main() {
     for (int k = 0; k < rr.first && k < 300000; ++k) diff += back[k] != big[k];
     printf("chunked_back %d %s %zu\n", rr.first, rr.second ? rr.second->msg.c_str() : "none", diff);
   }
+  // Writer on ONE long stream (the default, bit-exact mode): output reaches the sink while input is
+  // still arriving (Compressor::write, deflate.mbt:280-294), not only at close
+  {
+    std::vector<uint8_t> big(5 * 65535 + 4321);
+    uint32_t x = 777;
+    for (size_t i = 0; i < big.size(); ++i) {
+      x = x * 1664525u + 1013904223u;
+      big[i] = (uint8_t)("the quick brown fox "[(x >> 24) % 20]);
+    }
+    Buffer sink;
+    Writer sw(sink, eng, 0, 0, 2);  // hand over every two full windows
+    size_t at = 0, seen_before_close = 0;
+    while (at < big.size()) {
+      const size_t k = std::min<size_t>(50000, big.size() - at);
+      sw.write(big.data() + at, k);
+      at += k;
+      if (at < big.size()) seen_before_close = sink.bytes.size();
+    }
+    Err ce = sw.close();
+    printf("streamed %s %zu %zu\n", ce ? ce->msg.c_str() : "none", seen_before_close, sink.bytes.size());
+    hex("streamed_bytes", sink.bytes);
+    // Reader without a size hint: one size pass + one decode, no retries
+    BytesReader src(sink.bytes);
+    Reader r(src, eng);
+    std::vector<uint8_t> back(big.size() + 1);
+    auto rr = r.read(back.data(), back.size());
+    size_t diff = 0;
+    for (int k = 0; k < rr.first && (size_t)k < big.size(); ++k) diff += back[k] != big[k];
+    printf("streamed_back %d %s %zu\n", rr.first, rr.second ? rr.second->msg.c_str() : "none", diff);
+    // and a WRONG hint is corrected from the status code, not from a message
+    BytesReader src2(sink.bytes);
+    Reader r2(src2, eng, 1000);
+    auto r2r = r2.read(back.data(), back.size());
+    printf("wrong_hint %d %s\n", r2r.first, r2r.second ? r2r.second->msg.c_str() : "none");
+  }
   return 0;
 }

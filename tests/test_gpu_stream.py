@@ -1,0 +1,96 @@
+"""One long stream written in pieces (flate_hip_stream_*) and the size-only inflate pass
+(FLATE_HIP_SIZE_ONLY): the streaming behaviour of the reference's Writer / Reader for long single
+streams (deflate.mbt:280-294; inflate.mbt:382-407), checked against the oracle."""
+import numpy as np
+import pytest
+
+from util import flate, make_streams, raw_inflate
+
+pytestmark = pytest.mark.gpu
+W = 65535
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = flate.FlateEngine(0)
+    yield e
+    e.close()
+
+
+def _pieces(eng, data, cuts, compat_go=False):
+    """write() the stream in the given whole-window pieces, close() with the rest."""
+    w = eng.open_stream(compat_go=compat_go)
+    out, pos, emitted = [], 0, []
+    for k in cuts:
+        b = w.write(data[pos:pos + k * W])
+        emitted.append(len(b))
+        out.append(b)
+        pos += k * W
+    out.append(w.close(data[pos:]))
+    return np.concatenate(out).tobytes(), emitted
+
+
+@pytest.mark.parametrize("kind", ["text", "low", "runs", "period", "rand", "zero", "ramp"])
+def test_pieces_equal_the_one_shot_stream(eng, oracle, kind):
+    tails = [0, 1, 16, 17, 100, 127, 128, 5000, W - 1]
+    for t_i, tail in enumerate(tails):
+        nwin = 1 + t_i % 4
+        data, _ = make_streams([(kind, nwin * W + tail)], seed=77 + t_i)
+        data = data[:nwin * W + tail]
+        want = oracle.deflate(data)
+        cuts = [1] * nwin if t_i % 2 else ([nwin] if nwin < 3 else [1, nwin - 1])
+        got, emitted = _pieces(eng, data, cuts)
+        assert got == want, (kind, tail, cuts)
+        assert raw_inflate(got) == data.tobytes()
+        # output really leaves before close: every piece of compressible data hands bytes out
+        assert all(e > 0 for e in emitted), emitted
+
+
+def test_final_only_and_empty_streams(eng, oracle):
+    for n in (0, 1, 16, 17, 127, 128, 4000, W, W + 1):
+        data, _ = make_streams([("text", n)], seed=5)
+        data = data[:n]
+        got, _ = _pieces(eng, data, [])
+        assert got == oracle.deflate(data), n
+
+
+def test_go_compat_pieces(eng, oracle):
+    data, _ = make_streams([("text", 3 * W + 777)], seed=9)
+    data = data[:3 * W + 777]
+    got, _ = _pieces(eng, data, [1, 2], compat_go=True)
+    assert got == oracle.deflate(data, compat=oracle.COMPAT_GO)
+
+
+def test_sticky_rules(eng):
+    w = eng.open_stream()
+    with pytest.raises(flate.FlateError):
+        w.write(np.zeros(1000, np.uint8))  # not whole windows
+    data = flate.synth("text", 1, W)
+    assert len(w.write(data)) > 0          # an argument error is not sticky
+    w.close(b"abc")
+    w2 = eng.open_stream()
+    w2.close(b"")
+    with pytest.raises(flate.FlateError):
+        w2._write(np.zeros(W, np.uint8), False)  # after close
+
+
+def test_size_only_pass_gives_the_exact_sizes(eng, oracle):
+    specs = [("text", 70000), ("zero", 300000), ("rand", 5000), ("low", 0), ("runs", 131070), ("text", 17)]
+    data, off = make_streams(specs, seed=3)
+    comp, coff = eng.deflate_batch(data, off)
+    sizes, status, err_off = eng.inflate_sizes(comp, coff)
+    assert (status == 0).all() and sizes.tolist() == [n for _, n in specs]
+    # then the exact-size decode; nothing had to be guessed
+    back, boff, olen, st, _ = eng.inflate_batch(comp, coff, sizes)
+    assert (st == 0).all() and bytes(back[:int(boff[-1])]) == data[:int(off[-1])].tobytes()
+    # a broken stream: the size pass reports what the real pass reports
+    bad = np.array(comp[:int(coff[1])], copy=True)
+    bad[len(bad) // 2] ^= 0x55
+    boff1 = np.array([0, bad.size], np.uint64)
+    s1, st1, e1 = eng.inflate_sizes(bad, boff1)
+    rc, out, consumed, eoff = oracle.inflate(bad, 200000, full=True)
+    _, _, l2, st2, e2 = eng.inflate_batch(bad, boff1, [200000], check=False)
+    assert int(st1[0]) == int(st2[0]) and int(s1[0]) == int(l2[0]) == len(out) and int(e1[0]) == int(e2[0])
+    # truncated input
+    s3, st3, _ = eng.inflate_sizes(comp[:int(coff[1]) - 9], np.array([0, int(coff[1]) - 9], np.uint64))
+    assert int(st3[0]) == -7 and 0 < int(s3[0]) <= 70000

@@ -90,3 +90,14 @@ def test_host_mirror_matches_reference_behaviour(oracle):
     assert lines["chunked"] == "none %d" % len(ref) and got == ref
     assert zlib.decompressobj(-15).decompress(got) == bytes(big)
     assert lines["chunked_back"] == "300000 EOF 0"
+    # the default Writer on one long stream: bit-exact, and bytes reached the sink before close()
+    x, long_ = 777, bytearray()
+    for _ in range(5 * 65535 + 4321):
+        x = (x * 1664525 + 1013904223) & 0xFFFFFFFF
+        long_.append(b"the quick brown fox "[(x >> 24) % 20])
+    want_long = oracle.deflate(bytes(long_))
+    st, before, total = lines["streamed"].split()
+    assert st == "none" and int(total) == len(want_long) and 0 < int(before) < int(total)
+    assert bytes.fromhex(lines["streamed_bytes"]) == want_long
+    assert lines["streamed_back"] == "%d EOF 0" % len(long_)   # Reader without a size hint
+    assert lines["wrong_hint"] == "%d EOF" % len(long_)        # ... and with a wrong one
