@@ -92,6 +92,9 @@ int flate_hip_set_stream(flate_hip_ctx *ctx, void *hip_stream);
  *                        producing, the gate of an overlapped sub-batch) give up after this many
  *                        polls and the call returns FLATE_HIP_E_INTERNAL (default 8 Mi polls,
  *                        several seconds of a running wave; time spent preempted does not count)
+ *   "stream_rebase_bytes"  flate_hip_stream_*: a stream longer than this moves its origin up
+ *                        (what shift_offsets does in the reference, deflate-fast.mbt:366-389);
+ *                        default 1 GiB, read when the stream is opened; results never change
  *   "debug_drop_window_push"  test hook: k > 0 loses the k-th window hand-over of the next
  *                        multi-window launch, so that the bounded wait can be exercised */
 int flate_hip_set_option(flate_hip_ctx *ctx, const char *name, int64_t value);
@@ -126,7 +129,9 @@ int flate_hip_deflate_fast_batch(flate_hip_ctx *ctx, const uint8_t *in,
  *   n: a multiple of 65535 (whole windows) unless final; final != 0: any n (also 0), ends the
  *   stream with Writer::close's block (deflate.mbt:171-176).  in / out are HOST buffers;
  *   out_cap >= flate_hip_stream_bound(n).  Errors are sticky (Compressor.err, deflate.mbt:74):
- *   after a failed or a final write every further write fails.  One wavefront compresses one
+ *   after a failed or a final write every further write fails.  The stream may be of any length
+ *   (no 2 GiB limit here: the origin of its positions moves up as the reference's shift_offsets
+ *   does, deflate-fast.mbt:366-389); one piece is < 1 GiB.  One wavefront compresses one
  *   stream: this is the reference's semantics for a long stream, not the engine's fast path
  *   (batches of streams are). */
 typedef struct flate_hip_stream flate_hip_stream;

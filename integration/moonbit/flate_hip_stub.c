@@ -1,8 +1,9 @@
 /*
  * flate_hip_stub.c -- the few lines of C the MoonBit native backend needs next to
  * libflate_hip.so.  MoonBit's `extern "C"` cannot take
- * a pointer-to-pointer, so the context constructor is wrapped; everything else binds
- * include/flate_hip.h directly.  UNVERIFIED with moon (not available in the build image); this file
+ * a pointer-to-pointer and has no null test for an #external type, so the three constructors
+ * (ctx, comm, stream) and their null tests are wrapped, and the size-only inflate pass fixes its NULL
+ * arguments; everything else binds include/flate_hip.h directly.  UNVERIFIED with moon (not available in the build image); this file
  * itself is compiled by tests/test_library_abi.py to keep it in step with the header.
  */
 #include "flate_hip.h"
@@ -17,25 +18,9 @@ flate_hip_ctx *flate_hip_mbt_ctx_new(int device) {
 /* MoonBit has no null test for an #external type */
 int flate_hip_mbt_ctx_is_null(const flate_hip_ctx *c) { return c == 0; }
 
-/* MoonBit Int64/UInt64 FixedArrays are passed as plain pointers: these two calls only fix the
- * argument order and types the .mbt file declares. */
-int flate_hip_mbt_deflate_batch(flate_hip_ctx *c, const uint8_t *in, const uint64_t *in_off, uint32_t n,
-                                uint8_t *out, uint64_t out_cap, uint64_t *out_off, uint32_t flags) {
-  return flate_hip_deflate_fast_batch(c, in, in_off, n, out, out_cap, out_off, flags);
-}
-
-int flate_hip_mbt_inflate_batch(flate_hip_ctx *c, const uint8_t *in, const uint64_t *in_off, uint32_t n,
-                                uint8_t *out, const uint64_t *out_off, uint64_t *out_len, int32_t *status,
-                                int64_t *err_off, uint32_t flags) {
-  return flate_hip_inflate_batch(c, in, in_off, n, out, out_off, out_len, status, err_off, flags);
-}
-
-/* out_len is a one-element FixedArray[UInt64] on the MoonBit side */
-int flate_hip_mbt_deflate_spliced(flate_hip_ctx *c, const uint8_t *in, const uint64_t *in_off, uint32_t n,
-                                  uint8_t *out, uint64_t out_cap, uint64_t *out_len, uint64_t *bit_off,
-                                  uint32_t flags) {
-  return flate_hip_deflate_fast_spliced(c, in, in_off, n, out, out_cap, out_len, bit_off, flags);
-}
+/* (FixedArray[Byte] / FixedArray[UInt64] / FixedArray[Int] arrive as plain pointers, so
+ * flate_hip_deflate_fast_batch, flate_hip_inflate_batch, flate_hip_deflate_fast_spliced,
+ * flate_hip_stream_write and the gather calls are bound by the .mbt file directly: no wrapper.) */
 
 /* -- exchange step (multi-GPU): the communicator constructor returns its pointer instead of
  * writing it through a pointer-to-pointer; the gather calls bind include/flate_hip.h directly. -- */

@@ -90,6 +90,7 @@ struct flate_hip_ctx {
   // (a poll is one relaxed load + s_sleep, >= 0.4 us; a wave that is not running does not count)
   uint32_t spin_limit = 8u << 20;
   uint32_t inject_drop_push = 0;  // test hook: the k-th window hand-over (1-based) is dropped
+  uint64_t stream_rebase = 1ull << 30;  // flate_hip_stream: origin moved up past this many bytes
   hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
 };
 
@@ -526,6 +527,8 @@ int flate_hip_set_option(flate_hip_ctx *c, const char *name, int64_t value) {
     c->overlap_resident = (uint32_t)value;
   } else if (k == "spin_limit_polls" && value > 0 && value <= 0x7fffffff) {
     c->spin_limit = (uint32_t)value;
+  } else if (k == "stream_rebase_bytes" && value >= 65535 && value <= (1ll << 30)) {
+    c->stream_rebase = (uint64_t)value;
   } else if (k == "debug_drop_window_push" && value >= 0 && value <= 0x7fffffff) {
     c->inject_drop_push = (uint32_t)value;
 
@@ -722,6 +725,10 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
   HIP_TRY(c, hipMemcpyAsync(&c->h_status_word, c->d_status.p, 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (c->h_status_word) {
+    if (c->h_status_word == kStatusLanesLost) {
+      c->hip_err = "a persistent match-finder loop lost lanes of its wavefront (miscompiled loop?)";
+      return FLATE_HIP_E_INTERNAL;
+    }
     if (c->h_status_word == kStatusUqTimeout || c->h_status_word == kStatusGateTimeout ||
         c->h_status_word == kStatusBadIndex) {
       c->hip_err = c->h_status_word == kStatusUqTimeout
@@ -974,6 +981,8 @@ struct flate_hip_stream {
   uint32_t flags = 0;
   DevBuf table, clock, hist, stage, io, out;  // io: {lz77 in_off[2], huff in_off[2]} (u64) + chunk/blk bases
   uint64_t abs = 0;        // bytes of the stream consumed so far (a multiple of 65535 until the end)
+  uint64_t pos = 0;        // the same, counted from the stream's current origin (see rebase_at)
+  uint64_t rebase_at = 1ull << 30;  // origin moved up when pos passes this (option stream_rebase_bytes)
   uint32_t carry_bits = 0; // bits of the last, incomplete output byte (0..7) ...
   uint8_t carry = 0;       // ... and their value
   bool closed = false;
@@ -987,8 +996,16 @@ int stream_write_impl(flate_hip_stream *st, const uint8_t *in, uint64_t n, bool 
                       uint64_t out_cap, uint64_t *out_len) {
   flate_hip_ctx *c = st->ctx;
   HIP_TRY(c, hipSetDevice(c->device));
-  const uint64_t W0 = st->abs;
-  if (W0 + n >= 0x7ffe0000ull) return FLATE_HIP_E_TOO_LARGE;
+  // Positions inside the kernels are 32-bit and counted from the stream's origin.  A long stream
+  // moves its origin up (the reference's shift_offsets, deflate-fast.mbt:366-389: same distances,
+  // smaller numbers), so its length is not limited; one piece is (< 1 GiB).
+  if (n >= (1ull << 30)) return FLATE_HIP_E_TOO_LARGE;
+  uint32_t rebase = 0;
+  if (st->pos >= st->rebase_at && st->pos > (uint64_t)kMaxStoreBlockSize) {
+    rebase = (uint32_t)(st->pos - (uint64_t)kMaxStoreBlockSize);  // new origin: one window in front
+    st->pos = kMaxStoreBlockSize;
+  }
+  const uint64_t W0 = st->pos;
   const uint64_t full = n / kMaxStoreBlockSize, r = n % kMaxStoreBlockSize;
   const uint32_t nch = (uint32_t)(full + (r >= (uint64_t)kSmallLzMin ? 1 : 0));
   const uint32_t nblk = (uint32_t)(full + (r > 0 ? 1 : 0));
@@ -1033,7 +1050,9 @@ int stream_write_impl(flate_hip_stream *st, const uint8_t *in, uint64_t n, bool 
     P.spin_limit = c->spin_limit;
     P.win0 = win0;
     hipLaunchKernelGGL(lz77_resume_kernel, dim3(1), dim3(64), 0, c->stream, P, (uint16_t *)st->table.p,
-                       (uint32_t *)st->clock.p, nch);
+                       (uint32_t *)st->clock.p, nch, rebase);
+  } else if (rebase) {
+    st->pos += rebase;  // (nothing ran: the table still counts from the old origin)
   }
   const size_t nb = (size_t)nblk + 1;
   if ((rc = ensure(c, c->d_blk_hist, nb * 320 * 4))) return rc;
@@ -1100,7 +1119,8 @@ int stream_write_impl(flate_hip_stream *st, const uint8_t *in, uint64_t n, bool 
   if (st->carry_bits) HIP_TRY(c, hipMemcpyAsync(&st->carry, d_out + whole, 1, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (st->carry_bits) st->carry &= (uint8_t)((1u << st->carry_bits) - 1u);
-  st->abs = W0 + n;
+  st->pos += n;
+  st->abs += n;
   *out_len = whole;
   return FLATE_HIP_OK;
 }
@@ -1113,6 +1133,7 @@ int flate_hip_stream_open(flate_hip_ctx *c, uint32_t flags, flate_hip_stream **o
   flate_hip_stream *st = new flate_hip_stream();
   st->ctx = c;
   st->flags = flags;
+  st->rebase_at = c->stream_rebase;
   *out = st;
   return FLATE_HIP_OK;
 }

@@ -15,6 +15,7 @@ constexpr uint32_t kDoneCounters = 64;
 constexpr int kStatusUqTimeout = -8;     // uq_pop: the unit with my ticket was never pushed
 constexpr int kStatusGateTimeout = -9;   // wait_count_kernel: a sub-batch was never finished
 constexpr int kStatusBadIndex = -10;     // an index outside the scratch it addresses (never expected)
+constexpr int kStatusLanesLost = -11;    // a persistent loop is running without all 64 lanes
 
 struct LzParams {
   const uint8_t *in;
@@ -127,7 +128,10 @@ template <bool MULTI>
 __global__ void lz77_guest_kernel(LzParams P);
 // one stream continued from an earlier launch: table and sweep clock come from / go back to `table_io`,
 // `clock_io`; runs the nwin windows from P.win0 on
-__global__ void lz77_resume_kernel(LzParams P, uint16_t *table_io, uint32_t *clock_io, uint32_t nwin);
+// rebase != 0: every position the table and the clock hold is first moved down by that many bytes
+// (the stream's origin was moved up: what shift_offsets does for the reference, deflate-fast.mbt:366-389)
+__global__ void lz77_resume_kernel(LzParams P, uint16_t *table_io, uint32_t *clock_io, uint32_t nwin,
+                                   uint32_t rebase);
 __global__ void huff_hist_kernel(HuffParams P);
 __global__ void huff_code_kernel(HuffParams P);
 __global__ void huff_pack_kernel(HuffParams P);

@@ -716,6 +716,15 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
 // body next to the one at its start made the compiler peel lane 0 off the loop: see uq_pop); the
 // release covers the whole wavefront's stores: the wait the compiler emits in front of the L2
 // write-back is the wave's vmcnt, and a wave barrier precedes the call.
+// Every lane of the wavefront must still be in the persistent loop.  hipcc once peeled lane 0 off
+// such a loop (see uq_pop): the blocks then ran every later stream with lane 0 masked off and
+// produced wrong records silently.  The code shape that avoids it is kept, and this turns a
+// recurrence (a compiler upgrade) into FLATE_HIP_E_INTERNAL instead of wrong bytes.
+FLATE_D void all_lanes_here(const LzParams &P, int lane) {
+  const uint64_t here = __ballot(true);
+  if (here != ~0ull && lane == (int)__builtin_ctzll(here)) atomicExch(P.status, kStatusLanesLost);
+}
+
 FLATE_D void stream_done_lane0(const LzParams &P, uint32_t q) {
   if (!P.done) return;
   const uint32_t k = q >> P.done_shift;
@@ -850,6 +859,7 @@ __global__ __launch_bounds__(64) void lz77_wave_kernel(LzParams P) {
       const UqUnit u = uq_pop(P, push_word, lane);
       if (__builtin_amdgcn_readfirstlane((int)u.ok) == 0) break;
       push_word = (uint32_t)__builtin_amdgcn_readfirstlane((int)uq_run<false>(P, u, table, lane));
+      all_lanes_here(P, lane);
       ++mine;
     }
     if (P.taken && lane == 0) __hip_atomic_fetch_add(P.taken, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -875,6 +885,7 @@ __global__ __launch_bounds__(64) void lz77_wave_kernel(LzParams P) {
     __syncthreads();
     lz77_stream<MULTI>(P, P.stream_ids ? P.stream_ids[q] : q, table, lane);
     __syncthreads();
+    all_lanes_here(P, lane);
     prev = q;
     ++mine;
   }
@@ -901,6 +912,7 @@ __global__ __launch_bounds__(64) void lz77_guest_kernel(LzParams P) {
       const UqUnit u = uq_pop(P, push_word, lane);
       if (__builtin_amdgcn_readfirstlane((int)u.ok) == 0) break;
       push_word = (uint32_t)__builtin_amdgcn_readfirstlane((int)uq_run<true>(P, u, table, lane));
+      all_lanes_here(P, lane);
     }
     return;
   }
@@ -916,6 +928,7 @@ __global__ __launch_bounds__(64) void lz77_guest_kernel(LzParams P) {
     __syncthreads();
     lz77_stream<MULTI, true>(P, P.stream_ids[q], table, lane, 0, 0xffffffffu, nullptr, tags);
     __syncthreads();
+    all_lanes_here(P, lane);
     prev = q;
   }
 }
@@ -923,8 +936,13 @@ __global__ __launch_bounds__(64) void lz77_guest_kernel(LzParams P) {
 // A stream that continues across calls (flate_hip_stream_write): the table and the sweep clock rest
 // in global memory between the calls, exactly as between two window units (uq_run) -- but the next
 // launch is a later kernel on the same HIP stream, so plain loads and stores are enough.
+// rebase: the host has moved the stream's origin up by that many bytes (a multiple of 65535) so that
+// absolute positions stay small however long the stream grows -- the reference does the same to its
+// table offsets when `cur` nears 2^31 (shift_offsets, deflate-fast.mbt:366-389).  The slots hold
+// positions mod 2^16 (markers included), so every slot and the sweep clock move down by the same
+// amount and all distances stay what they were.
 __global__ __launch_bounds__(64) void lz77_resume_kernel(LzParams P, uint16_t *table_io, uint32_t *clock_io,
-                                                          uint32_t nwin) {
+                                                          uint32_t nwin, uint32_t rebase) {
   __shared__ uint16_t table[kTableSize];
   const int lane = threadIdx.x;
   uint32_t clock = 0;
@@ -932,7 +950,16 @@ __global__ __launch_bounds__(64) void lz77_resume_kernel(LzParams P, uint16_t *t
     const uint4 *src = reinterpret_cast<const uint4 *>(table_io);
     uint4 *dst = reinterpret_cast<uint4 *>(table);
     for (int i = lane; i < (int)(kTableSize * sizeof(uint16_t) / 16); i += 64) dst[i] = src[i];
-    clock = *clock_io;
+    clock = *clock_io - rebase;
+    if (rebase) {
+      __syncthreads();
+      uint32_t *t32 = reinterpret_cast<uint32_t *>(table);
+      const uint32_t d16 = rebase & 0xffffu;
+      for (int i = lane; i < kTableSize / 2; i += 64) {
+        const uint32_t v = t32[i];
+        t32[i] = ((v - d16) & 0xffffu) | ((((v >> 16) - d16) & 0xffffu) << 16);
+      }
+    }
   }
   __syncthreads();
   lz77_stream<true>(P, 0, table, lane, P.win0, P.win0 + nwin, &clock);

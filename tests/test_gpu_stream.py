@@ -94,3 +94,22 @@ def test_size_only_pass_gives_the_exact_sizes(eng, oracle):
     # truncated input
     s3, st3, _ = eng.inflate_sizes(comp[:int(coff[1]) - 9], np.array([0, int(coff[1]) - 9], np.uint64))
     assert int(st3[0]) == -7 and 0 < int(s3[0]) <= 70000
+
+
+def test_long_stream_moves_its_origin(oracle):
+    # flate_hip_stream has no length limit: past "stream_rebase_bytes" the origin of the positions the
+    # kernels work with moves up (the reference's shift_offsets, deflate-fast.mbt:366-389).  With the
+    # threshold lowered to two windows an 11-window stream rebases several times; the bytes stay those
+    # of the one-shot stream in both compat modes.
+    e = flate.FlateEngine(0)
+    try:
+        e.set_option("stream_rebase_bytes", 2 * W)
+        for kind, go in (("text", False), ("period", False), ("text", True), ("runs", False)):
+            n = 11 * W + 3000
+            data, _ = make_streams([(kind, n)], seed=41)
+            data = data[:n]
+            want = oracle.deflate(data, compat=oracle.COMPAT_GO if go else 0)
+            got, _ = _pieces(e, data, [1, 2, 1, 3, 2, 2], compat_go=go)
+            assert got == want, (kind, go)
+    finally:
+        e.close()
