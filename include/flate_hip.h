@@ -80,7 +80,13 @@ int flate_hip_set_stream(flate_hip_ctx *ctx, void *hip_stream);
  *                        on >= 64 MiB: the batch is cut into this many groups of streams (each at
  *                        least 4096 streams, for inflate 16384) and
  *                        group g is compressed while group g+1 is copied in and the output of g-1
- *                        is copied out (default 4; 0 or 1: copy in, compress, copy out)
+ *                        is copied out (default 4; 0 or 1: copy in, compress, copy out).  The
+ *                        groups hold equal BYTES (not equal stream counts).  Such a call starts
+ *                        two copy threads of its own for its duration.  If it fails part-way
+ *                        (FLATE_HIP_E_OUT_TOO_SMALL, a HIP error) out and out_off are partly
+ *                        written and must not be used; inflate: a failing stream does not stop
+ *                        the batch, every stream's status is reported as in one pass
+ *   "host_pipeline_group_streams"  smallest group of such a call (default 4096 streams)
  *   "overlap_sub_batches"  > 0: the entropy kernels of every sub-batch (queue order) run on a
  *                        second HIP stream as soon as the match finder has counted its streams
  *                        done (default 0: measured slower on MI355X)

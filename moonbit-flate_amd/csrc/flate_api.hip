@@ -86,6 +86,7 @@ struct flate_hip_ctx {
   // and group g is compressed while group g+1 is copied in and the output of group g-1 is copied
   // out (two copy threads on two non-blocking streams).  0 = one copy in, compress, one copy out.
   int host_groups = 4;
+  uint32_t host_group_streams = 4096;  // a group holds at least this many streams
   // bounded waits of the persistent kernels (uq_pop, wait_count_kernel): polls before giving up
   // (a poll is one relaxed load + s_sleep, >= 0.4 us; a wave that is not running does not count)
   uint32_t spin_limit = 8u << 20;
@@ -517,6 +518,8 @@ int flate_hip_set_option(flate_hip_ctx *c, const char *name, int64_t value) {
     c->resident_blocks = (uint32_t)value;
   } else if (k == "host_pipeline_groups" && value >= 0 && value <= 64) {
     c->host_groups = (int)value;
+  } else if (k == "host_pipeline_group_streams" && value > 0 && value <= 0x7fffffff) {
+    c->host_group_streams = (uint32_t)value;
   } else if (k == "profile_split_streams" && value >= 0 && value <= 0x7fffffff) {
     c->profile_split = (uint32_t)value;
   } else if (k == "window_units" && (value == 0 || value == 1)) {
@@ -863,6 +866,22 @@ class CopyPipe {
   std::thread t_in_, t_out_;
 };
 
+// Group boundaries of a host-pointer batch: group g ends at the first stream where the running byte
+// count (a, plus b when given) reaches g / G of the total -- streams of very different sizes still
+// give groups of equal work.  lo has G + 1 entries, lo[0] = 0, lo[G] = n, non-decreasing.
+void cut_by_bytes(const uint64_t *a, const uint64_t *b, uint32_t n, uint32_t G, std::vector<uint32_t> &lo) {
+  auto at = [&](uint32_t i) { return (a[i] - a[0]) + (b ? b[i] - b[0] : 0ull); };
+  const uint64_t total = at(n);
+  lo[0] = 0;
+  uint32_t i = 0;
+  for (uint32_t g = 1; g < G; ++g) {
+    const uint64_t want = total / G * g;
+    while (i < n && at(i) < want) ++i;
+    lo[g] = i;
+  }
+  lo[G] = n;
+}
+
 int host_pipe_streams(flate_hip_ctx *c) {
   if (!c->h2d_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking));
   if (!c->d2h_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
@@ -880,9 +899,9 @@ static int deflate_host_pipelined(flate_hip_ctx *c, const uint8_t *in, const uin
   if ((rc = ensure(c, c->d_out, out_cap + 16))) return rc;
   if ((rc = host_pipe_streams(c))) return rc;
   uint8_t *d_in = (uint8_t *)c->d_in.p, *d_out = (uint8_t *)c->d_out.p;
-  std::vector<uint32_t> lo(G + 1);  // equal stream counts (the streams of one batch are of similar size)
+  std::vector<uint32_t> lo(G + 1);
   std::vector<CopyJob> in_jobs(G);
-  for (uint32_t g = 0; g <= G; ++g) lo[g] = (uint32_t)((uint64_t)n * g / G);
+  cut_by_bytes(in_off, nullptr, n, G, lo);  // equal BYTES per group: copy and compute stages stay balanced
   for (uint32_t g = 0; g < G; ++g)
     in_jobs[g] = {d_in + in_off[lo[g]], in + in_off[lo[g]], (size_t)(in_off[lo[g + 1]] - in_off[lo[g]])};
   CopyPipe pipe(G, G);
@@ -934,7 +953,8 @@ int flate_hip_deflate_fast_batch(flate_hip_ctx *c, const uint8_t *in, const uint
   // host pointers and a batch large enough that every group still fills the persistent launch
   if (!(flags & FLATE_HIP_DEVICE_PTRS) && c->host_groups > 1 && in_off[n] >= (64ull << 20)) {
     uint32_t G = (uint32_t)c->host_groups;
-    const uint32_t per = c->guest_min > 4096u ? c->guest_min : 4096u;  // (a group of 4096 still runs at 80 %)
+    // (a group of 4096 64-KiB streams still runs at 80 %; option host_pipeline_group_streams)
+    const uint32_t per = c->guest_min > c->host_group_streams ? c->guest_min : c->host_group_streams;
     if (n / per < G) G = n / per;
     if (G > 1) {
       StagePlan pl;  // validate the whole index first (the same checks as the one-call path)
@@ -1306,7 +1326,7 @@ static int inflate_host_pipelined(flate_hip_ctx *c, const uint8_t *in, const uin
   uint8_t *d_in = (uint8_t *)c->d_in.p, *d_out = (uint8_t *)c->d_out.p;
   std::vector<uint32_t> lo(G + 1);
   std::vector<CopyJob> in_jobs(G);
-  for (uint32_t g = 0; g <= G; ++g) lo[g] = (uint32_t)((uint64_t)n * g / G);
+  cut_by_bytes(in_off, out_off, n, G, lo);  // by input + output bytes (both cross PCIe)
   for (uint32_t g = 0; g < G; ++g)
     in_jobs[g] = {d_in + in_off[lo[g]], in + in_off[lo[g]], (size_t)(in_off[lo[g + 1]] - in_off[lo[g]])};
   CopyPipe pipe(G, G);
@@ -1372,7 +1392,8 @@ int flate_hip_inflate_batch(flate_hip_ctx *c, const uint8_t *in, const uint64_t 
   if (!(flags & FLATE_HIP_DEVICE_PTRS) && c->host_groups > 1 &&
       in_off[n] - in_off[0] + out_off[n] - out_off[0] >= (64ull << 20)) {
     uint32_t G = (uint32_t)c->host_groups;
-    if (n / 16384u < G) G = n / 16384u;  // (a group should still fill the lane-per-stream launch)
+    const uint32_t iper = 4u * c->host_group_streams;  // (a group should still fill the lane-per-stream launch: 16384)
+    if (n / iper < G) G = n / iper;
     if (G > 1) {
       try {
         return inflate_host_pipelined(c, in, in_off, n, out, out_off, out_len, status, err_off, flags, G);

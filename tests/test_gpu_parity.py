@@ -318,3 +318,34 @@ def test_host_pointer_pipeline_matches_single_pass(oracle):
             e.deflate_batch(host, off, out_cap=int(o0[-1]) // 2)
     finally:
         e.close()
+
+
+def test_host_pointer_pipeline_uneven_streams_three_groups(oracle):
+    # groups are cut by BYTES: streams of very different sizes, three and four groups, same bytes and
+    # the same index as one pass (and as the oracle on a sample)
+    rng = np.random.default_rng(17)
+    lens = np.where(rng.random(2300) < 0.3, rng.integers(60000, 140000, 2300), rng.integers(0, 9000, 2300))
+    lens[:40] = 0
+    specs = [("text", int(l)) for l in lens]
+    host, off = make_streams(specs, seed=8)
+    assert int(off[-1]) >= (64 << 20)
+    e = flate.FlateEngine(0)
+    try:
+        e.set_option("guest_min_streams", 1)
+        e.set_option("host_pipeline_group_streams", 250)
+        e.set_option("host_pipeline_groups", 0)
+        c0, o0 = e.deflate_batch(host, off)
+        total = int(o0[-1])
+        for groups in (3, 4):
+            e.set_option("host_pipeline_groups", groups)
+            c1, o1 = e.deflate_batch(host, off)
+            assert np.array_equal(np.asarray(o0), np.asarray(o1)), groups
+            assert np.array_equal(np.asarray(c0)[:total], np.asarray(c1)[:total]), groups
+        c = np.asarray(c1)
+        for i in range(0, len(specs), 97):
+            assert bytes(c[int(o1[i]):int(o1[i + 1])]) == oracle.deflate(host[int(off[i]):int(off[i + 1])]), i
+        # and back, through the pipelined inflate (it cuts by input + output bytes)
+        back, boff, olen, st, _ = e.inflate_batch(c[:total], o1, lens)
+        assert (st == 0).all() and np.array_equal(np.asarray(back)[:int(boff[-1])], host[:int(off[-1])])
+    finally:
+        e.close()
