@@ -92,6 +92,9 @@ int flate_hip_set_stream(flate_hip_ctx *ctx, void *hip_stream);
  *                        done (default 0: measured slower on MI355X)
  *   "inflate_simt_min_streams"  inflate batches at least this large decode one stream per LANE
  *                        (64 per wavefront) instead of one per wavefront (default 2049)
+ *   "inflate_spec"       the third decoder -- one wavefront per stream, 64 token starts decoded
+ *                        speculatively at once: 0 = never, 1 = for batches below
+ *                        "inflate_spec_max_streams" streams, 2 = always
  *   "inflate_lanes"      streams per wavefront of that decoder: 0 = chosen from the batch size
  *                        (default), or 16 / 32 / 64
  *   "spin_limit_polls"   the persistent kernels' waits (a window that another block is still

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libflate_hip.so")
 
 SOURCES = ["lz77_kernels.hip",  "huff_pack_kernels.hip", "compact_kernels.hip",
            "inflate_kernels.hip", "splice_kernels.hip", "flate_api.hip", "gather.hip", "synth.cpp"]
-HEADERS = ["flate_common.h", "flate_kernels.h", "lz77_device.h", os.path.join(ROOT, "include", "flate_hip.h")]
+HEADERS = ["flate_common.h", "flate_kernels.h", "lz77_device.h", "inflate_spec_kernel.inc", os.path.join(ROOT, "include", "flate_hip.h")]
 
 
 def source_hash():

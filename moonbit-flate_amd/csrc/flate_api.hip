@@ -59,6 +59,12 @@ struct flate_hip_ctx {
   // streams whatever the batch size, the wave-per-stream one ~13 ms per 1024 streams (measured:
   // tools/inflate_crossover.py)
   uint32_t inflate_simt_min = 2049;
+  // the speculative wave-per-stream decoder (inflate_spec_kernel): 0 = never, 1 = for batches below
+  // inflate_spec_max streams (where it beats both other decoders), 2 = always (tests)
+  int inflate_spec = 1;
+  uint32_t inflate_spec_max = 14336;  // measured (tools/inflate_crossover.py): 1024 streams 5 ms against 13.7
+                                      // (wave per stream) and 27 (lane per stream); 4096: 13 / 52 / 25;
+                                      // 16384: 28 vs 29 for the lane-per-stream decoder, which wins beyond
   uint32_t resident_blocks = 1024;  // persistent LDS-table blocks (4 per CU x 256 CUs)
   // Entropy stage overlapped with the match finder: the batch is cut into overlap_sub sub-batches
   // (queue order); hist/code/scan/pack of a sub-batch run on ent_stream as soon as the match finder
@@ -514,6 +520,10 @@ int flate_hip_set_option(flate_hip_ctx *c, const char *name, int64_t value) {
     c->inflate_lanes = (int)value;
   } else if (k == "inflate_simt_min_streams" && value >= 0) {
     c->inflate_simt_min = (uint32_t)value;
+  } else if (k == "inflate_spec" && value >= 0 && value <= 2) {
+    c->inflate_spec = (int)value;
+  } else if (k == "inflate_spec_max_streams" && value >= 0 && value <= 0x7fffffff) {
+    c->inflate_spec_max = (uint32_t)value;
   } else if (k == "resident_blocks" && value > 0 && value <= 65536) {
     c->resident_blocks = (uint32_t)value;
   } else if (k == "host_pipeline_groups" && value >= 0 && value <= 64) {
@@ -1285,7 +1295,11 @@ static int inflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
     // lane-per-stream one reads its history back from the output it has written)
     bool simt = (spliced || n >= c->inflate_simt_min) && !size_only;
     for (uint32_t i = 0; i < n && simt && !spliced; ++i) simt = in_off[i + 1] - in_off[i] < (1ull << 28);
-    if (simt) {
+    bool spec = !spliced && !size_only && (c->inflate_spec == 2 || (c->inflate_spec == 1 && n < c->inflate_spec_max));
+    for (uint32_t i = 0; i < n && spec; ++i) spec = in_off[i + 1] - in_off[i] < (1ull << 28);  // 32-bit bit positions
+    if (spec) {
+      hipLaunchKernelGGL(inflate_spec_kernel, dim3(n), dim3(64), 0, c->stream, I);
+    } else if (simt) {
       // streams per wavefront: as many as still leave four wavefronts (one per SIMD) per CU
       int lpw = c->inflate_lanes;
       if (lpw == 0) lpw = n >= 256u * c->num_cus ? 64 : (n >= 128u * c->num_cus ? 32 : 16);

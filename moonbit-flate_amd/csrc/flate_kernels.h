@@ -141,6 +141,7 @@ __global__ void scan_sizes_kernel(CompactParams P);
 // finder that is still running on another stream
 __global__ void wait_count_kernel(const uint32_t *counter, uint32_t target, int *status, uint32_t spin_limit);
 __global__ void inflate_kernel(InfParams P);
+__global__ void inflate_spec_kernel(InfParams P);  // one wavefront per stream, 64 token starts decoded at once
 template <int LPW>
 __global__ void inflate_simt_kernel(InfParams P);
 

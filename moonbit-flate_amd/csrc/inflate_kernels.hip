@@ -539,6 +539,8 @@ __global__ __launch_bounds__(64) void inflate_kernel(InfParams P) {
   }
 }
 
+#include "inflate_spec_kernel.inc"
+
 }  // namespace flate
 
 // =======================================================================================

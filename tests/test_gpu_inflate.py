@@ -9,12 +9,13 @@ from util import flate, make_streams
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["wave_per_stream", "lane_per_stream"])
+@pytest.fixture(scope="module", params=["wave_per_stream", "lane_per_stream", "speculative_wave"])
 def eng(request):
-    """Both inflater kernels must pass every test: the option forces one or the other."""
+    """All three inflater kernels must pass every test: the options force one of them."""
     flate.build()
     e = flate.FlateEngine(0)
     e.set_option("inflate_simt_min_streams", 0 if request.param == "lane_per_stream" else 1 << 30)
+    e.set_option("inflate_spec", 2 if request.param == "speculative_wave" else 0)
     yield e
     e.close()
 

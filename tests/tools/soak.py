@@ -40,12 +40,14 @@ while time.time() - t0 < budget:
     assert bytes(one[:nb]) == rs and np.array_equal(bit_off, rbo), "spliced differs (%s)" % tag
     szs = [s for _, s in specs]
     comp = np.concatenate([out[:int(ooff[-1])], np.zeros(8, np.uint8)])
-    for simt_min in (0, 1 << 30):
+    for simt_min, spec in ((0, 0), (1 << 30, 0), (1 << 30, 2)):  # lane per stream, wave per stream, speculative wave
         eng.set_option("inflate_simt_min_streams", simt_min)
+        eng.set_option("inflate_spec", spec)
         eng.set_option("inflate_lanes", int(rng.choice([0, 16, 32, 64])))
         back, _, olen, status, _ = eng.inflate_batch(comp, ooff, szs)
         assert (status == 0).all() and list(olen) == szs, "inflate status (%s)" % tag
         assert bytes(back[:int(off[-1])]) == data[:int(off[-1])].tobytes(), "inflate bytes (%s)" % tag
+    eng.set_option("inflate_spec", 1)
     back, _, olen, status, _ = eng.inflate_spliced(np.concatenate([one[:nb], np.zeros(8, np.uint8)]), nb, bit_off, szs)
     assert (status == 0).all() and bytes(back[:int(off[-1])]) == data[:int(off[-1])].tobytes(), "inflate_spliced (%s)" % tag
     if rounds % 7 == 3:  # a uniform batch: the overlapped entropy stage is eligible
