@@ -88,7 +88,7 @@ def cpu_info():
     return {"nproc": os.cpu_count() or 1, "model": model}
 
 
-def pmc_traffic(name, key, flate, args):
+def pmc_traffic(name, key, flate, args, group="lz77"):
     """HBM bytes per launch from the rocprofv3 --pmc passes kept in profiles/ (FETCH_SIZE and
     WRITE_SIZE collected in separate passes, units/corrections as MI355X_MICROARCH.md prescribes:
     see profiles/r02/README.md) -- but only when that collection describes the code being timed:
@@ -96,7 +96,7 @@ def pmc_traffic(name, key, flate, args):
     flate_hip_build_id) and the run must use the default launch options.  Returns
     (bytes or None, info dict for the bench line)."""
     tuned = bool(args.option) or args.no_guests
-    lib_id = flate.build_id()
+    lib_id = flate.id_component(flate.build_id(), group)
     for rnd in ("r03", "r02"):
         path = os.path.join(ROOT, "profiles", rnd, name)
         try:
@@ -104,9 +104,10 @@ def pmc_traffic(name, key, flate, args):
             val = int(d["hbm_bytes_per_launch"])
         except Exception:
             continue
-        src = {"file": "profiles/%s/%s" % (rnd, name), "collected_on_build": d.get("build_id"),
+        got_id = flate.id_component(d.get("build_id"), group)
+        src = {"file": "profiles/%s/%s" % (rnd, name), "kernels": group, "collected_on_build": got_id,
                "git_head": d.get("git_head"), "this_build": lib_id}
-        if tuned or d.get("build_id") != lib_id:
+        if tuned or got_id is None or got_id != lib_id:
             src["traffic_stale"] = True  # other sources, or non-default launch options: not quoted
             return None, src
         return val, src
@@ -573,7 +574,8 @@ def bench_inflate(args, env, d_in, in_off, n, blen, host=None, steps=None, warmu
     achieved = (n * blen + clen) / (k_ms * 1e-3) / 1e9
     traffic, traffic_src = None, None
     if args.kind == "text" and blen == 65536 and n == 131072 and not args.spliced:
-        traffic, traffic_src = pmc_traffic("inflate_traffic.json", "inflate_131072x65536_text", env["flate"], args)
+        traffic, traffic_src = pmc_traffic("inflate_traffic.json", "inflate_131072x65536_text", env["flate"], args,
+                                           group="inflate")
     return {
         "metric": "GiB/s decompressed output (inflate), 64 KiB streams", "unit": "GiB/s",
         "value": round(world * n * blen * steps / dt / 2**30, 3), "n_gpus": world,

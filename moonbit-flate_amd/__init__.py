@@ -13,6 +13,11 @@ def source_hash():
     return _build.source_hash()
 
 
+def id_component(build_id, group):
+    """One kernel family's hash ("lz77", "huff", "inflate", "all") out of a build id string."""
+    return _build.id_component(build_id, group)
+
+
 def build(force=False, verbose=False):
     """Compile libflate_hip.so for gfx950 (hipcc)."""
     return _build.build(force=force, verbose=verbose)

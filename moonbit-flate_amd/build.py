@@ -14,19 +14,45 @@ SOURCES = ["lz77_kernels.hip",  "huff_pack_kernels.hip", "compact_kernels.hip",
 HEADERS = ["flate_common.h", "flate_kernels.h", "lz77_device.h", "inflate_spec_kernel.inc", os.path.join(ROOT, "include", "flate_hip.h")]
 
 
-def source_hash():
-    """16 hex digits over every source and header the library is built from (name + contents).
-    Compiled into the library (flate_hip_build_id) and written beside every PMC collection in
-    profiles/, so that a bench line can tell whether a collected figure describes this code."""
+GROUPS = {  # which sources a kernel family's measurements depend on (besides the shared headers / ABI)
+    "lz77": ["lz77_kernels.hip", "lz77_device.h"],
+    "huff": ["huff_pack_kernels.hip", "compact_kernels.hip", "splice_kernels.hip"],
+    "inflate": ["inflate_kernels.hip", "inflate_spec_kernel.inc"],
+}
+SHARED = ["flate_common.h", "flate_kernels.h", "flate_api.hip"]
+
+
+def _hash_files(names):
     import hashlib
     h = hashlib.sha256()
-    files = [os.path.join(CSRC, s) for s in SOURCES] + \
-            [x if os.path.isabs(x) else os.path.join(CSRC, x) for x in HEADERS]
-    for f in sorted(files, key=os.path.basename):
+    for n in sorted(names):
+        f = n if os.path.isabs(n) else os.path.join(CSRC, n)
         if os.path.exists(f):
             h.update(os.path.basename(f).encode() + b"\0")
             h.update(open(f, "rb").read())
-    return h.hexdigest()[:16]
+    return h.hexdigest()[:12]
+
+
+def source_hash():
+    """'all:<h>;lz77:<h>;huff:<h>;inflate:<h>' -- hashes over the sources the library is built from:
+    everything, and per kernel family (its own files + the shared headers and the ABI file).
+    Compiled into the library (flate_hip_build_id) and written beside every PMC collection in
+    profiles/, so that a bench line can tell whether a collected figure describes the kernels it
+    times (a change to the inflater does not stale the match finder's traffic figure)."""
+    everything = SOURCES + [h for h in HEADERS]
+    parts = ["all:" + _hash_files(everything)]
+    for g, files in GROUPS.items():
+        parts.append(g + ":" + _hash_files(files + SHARED))
+    return ";".join(parts)
+
+
+def id_component(build_id, group):
+    """The `group` hash of a build id string (None if absent)."""
+    for part in (build_id or "").split(";"):
+        k, _, v = part.partition(":")
+        if k == group:
+            return v
+    return None
 
 
 def _stale():
