@@ -62,10 +62,10 @@ struct flate_hip_ctx {
   // the speculative wave-per-stream decoder (inflate_spec_kernel): 0 = never, 1 = for batches below
   // inflate_spec_max streams (where it beats both other decoders), 2 = always (tests)
   int inflate_spec = 1;
-  uint32_t inflate_spec_max = 14336;  // measured (tools/inflate_crossover.py): 1024 streams 5 ms against 13.7
-                                      // (wave per stream) and 27 (lane per stream); 4096: 13 / 52 / 25;
-                                      // 16384: 28 vs 29 for the lane-per-stream decoder, which wins beyond
-  uint32_t resident_blocks = 1024;  // persistent LDS-table blocks (4 per CU x 256 CUs)
+  uint32_t inflate_spec_max = 18432;  // measured (tools/inflate_crossover.py, ms per batch of 64 KiB streams):
+                                      // 1024 streams 4.6 against 13.7 (wave per stream) and 27 (lane per
+                                      // stream); 4096: 9.3 / 52 / 25; 8192: 14.7 / - / 26; 16384: 26.1 / - / 29.2;
+                                      // 32768: 49 / - / 30.5 -- the lane-per-stream decoder wins from ~18 k streams on
   // Entropy stage overlapped with the match finder: the batch is cut into overlap_sub sub-batches
   // (queue order); hist/code/scan/pack of a sub-batch run on ent_stream as soon as the match finder
   // -- one launch over the whole batch -- has counted all of its streams done.  0 = off (default:
