@@ -66,6 +66,7 @@ struct flate_hip_ctx {
                                       // 1024 streams 4.6 against 13.7 (wave per stream) and 27 (lane per
                                       // stream); 4096: 9.3 / 52 / 25; 8192: 14.7 / - / 26; 16384: 26.1 / - / 29.2;
                                       // 32768: 49 / - / 30.5 -- the lane-per-stream decoder wins from ~18 k streams on
+  uint32_t resident_blocks = 1024;  // persistent LDS-table blocks (4 per CU x 256 CUs)
   // Entropy stage overlapped with the match finder: the batch is cut into overlap_sub sub-batches
   // (queue order); hist/code/scan/pack of a sub-batch run on ent_stream as soon as the match finder
   // -- one launch over the whole batch -- has counted all of its streams done.  0 = off (default:
