@@ -817,7 +817,7 @@ __global__ void uq_init_kernel(uint32_t *ready, uint32_t *ctr, uint32_t n_stream
 // go past L1 and are written through L2 -- every storing lane drains its stores, then one lane
 // publishes the ready word; the consumer polls that word and acquires once (uq_pop).
 template <bool GUEST>
-FLATE_D uint32_t uq_run(const LzParams &P, const UqUnit u, uint16_t *table, int lane) {
+FLATE_D uint32_t uq_run(const LzParams &P, const UqUnit u, uint16_t *table, int lane, uint32_t *tags = nullptr) {
   // (wave-uniform values made scalar explicitly: with a per-lane `nch` the branch around the push
   // below is divergent for the compiler, which then peels lane 0 off the unit loop)
   const uint32_t sid = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.stream_ids[u.q]);
@@ -833,7 +833,24 @@ FLATE_D uint32_t uq_run(const LzParams &P, const UqUnit u, uint16_t *table, int 
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
-  lz77_stream<true, GUEST>(P, sid, table, lane, u.c, u.c + 1, &clock);
+  if (tags && u.c != 0) {
+    // The table has just arrived from another block (an LDS-table block keeps no tags, and a guest's
+    // tags stay behind in its LDS): rebuild the slot tags from the bytes the slots point at.  16384
+    // four-byte gathers, < 1 % of a window's time.  A slot holds (position + 1) mod 2^16 of a position
+    // at most kMarkerBack behind this window's start W (older ones were swept to a marker, which is
+    // out of range for every lookup whatever its tag says).
+    const uint64_t a0 = P.in_off[sid];
+    const uint8_t *stream = P.in + a0;
+    const uint32_t W = u.c * (uint32_t)kMaxStoreBlockSize;
+    for (int i = lane; i < kTableSize / 16; i += 64) tags[i] = 0;
+    __syncthreads();
+    for (int h = lane; h < kTableSize; h += 64) {
+      const uint32_t back = (W + 1u - (uint32_t)table[h]) & 0xffffu;  // W - position
+      if (back != 0u && back <= W) tag_set(tags, (uint32_t)h, tag_of(ld32(stream + (W - back))));
+    }
+    __syncthreads();
+  }
+  lz77_stream<true, GUEST>(P, sid, table, lane, u.c, u.c + 1, &clock, tags);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
   if (u.c + 1 < nch) {
@@ -901,17 +918,17 @@ __global__ __launch_bounds__(64) void lz77_guest_kernel(LzParams P) {
   if (blockIdx.x >= P.gtable_blocks) return;  // (gtables holds one table per block of this launch)
   uint16_t *table = reinterpret_cast<uint16_t *>(P.gtables) + (size_t)blockIdx.x * kTableSize;
   const int lane = threadIdx.x;
-  uint32_t *tags = nullptr;
-  if constexpr (!MULTI) {  // multi-window streams gain nothing from it (profiles/r02/README.md)
-    __shared__ uint32_t tag_mem[kTableSize / 16];  // 4 KiB: see tag_of
-    tags = tag_mem;
-  }
+  // (round 2 gave multi-window guests no tags: -7 % with them at equal geometry, but the window
+  // units hand a stream from block to block and the tags did not travel; round 3 rebuilds them at the
+  // start of a unit instead, see uq_run)
+  __shared__ uint32_t tag_mem[kTableSize / 16];  // 4 KiB: see tag_of
+  uint32_t *tags = tag_mem;
   if (MULTI && P.uq_ready) {  // persistent, one window at a time, table in place (see uq_run)
     uint32_t push_word = 0;
     for (;;) {
       const UqUnit u = uq_pop(P, push_word, lane);
       if (__builtin_amdgcn_readfirstlane((int)u.ok) == 0) break;
-      push_word = (uint32_t)__builtin_amdgcn_readfirstlane((int)uq_run<true>(P, u, table, lane));
+      push_word = (uint32_t)__builtin_amdgcn_readfirstlane((int)uq_run<true>(P, u, table, lane, tags));
       all_lanes_here(P, lane);
     }
     return;
