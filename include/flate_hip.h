@@ -90,6 +90,9 @@ int flate_hip_set_stream(flate_hip_ctx *ctx, void *hip_stream);
  *   "overlap_sub_batches"  > 0: the entropy kernels of every sub-batch (queue order) run on a
  *                        second HIP stream as soon as the match finder has counted its streams
  *                        done (default 0: measured slower on MI355X)
+ *   "entropy_per_block"  -1 (default): the histogram and pack kernels run one wavefront per BLOCK
+ *                        instead of per stream when the batch's streams have three or more blocks
+ *                        on average; 0 = never; 1 = whenever every stream has a block
  *   "inflate_simt_min_streams"  inflate batches at least this large decode one stream per LANE
  *                        (64 per wavefront) instead of one per wavefront (default 2049)
  *   "inflate_spec"       the third decoder -- one wavefront per stream, 64 token starts decoded

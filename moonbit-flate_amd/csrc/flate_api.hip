@@ -45,7 +45,10 @@ struct flate_hip_ctx {
   // grow-only scratch
   DevBuf d_in, d_out, d_in_off, d_chunk_base, d_ids16, d_ids32, d_matches, d_nmatch, d_ntok;
   DevBuf d_slot_off, d_out_len, d_out_off, d_status;
-  DevBuf d_blk_base, d_blk_hist, d_blk_cl, d_blk_hdr, d_blk_meta, d_tile_meta;
+  DevBuf d_blk_base, d_blk_hist, d_blk_cl, d_blk_hdr, d_blk_meta, d_tile_meta, d_blk_sid;
+  // entropy stage with one wavefront per BLOCK instead of per stream: -1 = when the batch's streams
+  // have three or more blocks on average (multi-window streams), 0 = never, 1 = whenever possible
+  int entropy_per_block = -1;
   DevBuf d_istatus, d_ierr, d_debug, d_gtables, d_queue;
   hipStream_t guest_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -484,7 +487,7 @@ void flate_hip_destroy(flate_hip_ctx *c) {
   if (c->d2h_stream) (void)hipStreamDestroy(c->d2h_stream);
   for (DevBuf *b : {&c->scan_tab, &c->d_in, &c->d_out, &c->d_in_off, &c->d_chunk_base, &c->d_ids16,
                     &c->d_ids32, &c->d_matches, &c->d_nmatch, &c->d_ntok, &c->d_blk_base,
-                    &c->d_blk_hist, &c->d_blk_cl, &c->d_blk_hdr, &c->d_blk_meta, &c->d_tile_meta, &c->d_slot_off, &c->d_out_len, &c->d_out_off, &c->d_status, &c->d_istatus,
+                    &c->d_blk_hist, &c->d_blk_cl, &c->d_blk_hdr, &c->d_blk_meta, &c->d_tile_meta, &c->d_blk_sid, &c->d_slot_off, &c->d_out_len, &c->d_out_off, &c->d_status, &c->d_istatus,
                     &c->d_ierr, &c->d_debug, &c->d_gtables, &c->d_queue})
     release(*b);
   for (auto &e : c->ev)
@@ -541,6 +544,8 @@ int flate_hip_set_option(flate_hip_ctx *c, const char *name, int64_t value) {
     c->overlap_resident = (uint32_t)value;
   } else if (k == "spin_limit_polls" && value > 0 && value <= 0x7fffffff) {
     c->spin_limit = (uint32_t)value;
+  } else if (k == "entropy_per_block" && value >= -1 && value <= 1) {
+    c->entropy_per_block = (int)value;
   } else if (k == "stream_rebase_bytes" && value >= 65535 && value <= (1ll << 30)) {
     c->stream_rebase = (uint64_t)value;
   } else if (k == "debug_drop_window_push" && value >= 0 && value <= 0x7fffffff) {
@@ -620,6 +625,24 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
   HIP_TRY(c, hipMemcpyAsync(c->d_blk_base.p, pl.blk_base.data(), ((size_t)n + 1) * 4,
                             hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemsetAsync(c->d_status.p, 0, 4, c->stream));
+  // One wavefront per block in the histogram and pack kernels when the streams have many blocks
+  // (4096 streams of four windows are 4096 wavefronts per stream-kernel, a quarter of what fills
+  // the chip).  Every stream needs at least one block (a stream without any has nobody to write
+  // its closing block in that form).  Not for spliced output: where a block starts then depends on
+  // the bit its stream starts at (a stored block pads to a byte of the SPLICED stream), which only the
+  // stream's own walk knows.
+  bool per_block = c->entropy_per_block != 0 && pl.n_blocks > 0 && c->overlap_sub == 0 && !spliced &&
+                   (c->entropy_per_block == 1 || (uint64_t)pl.n_blocks >= 3ull * n);
+  for (uint32_t i = 0; i < n && per_block; ++i) per_block = pl.blk_base[i + 1] > pl.blk_base[i];
+  std::vector<uint32_t> blk_sid;
+  if (per_block) {
+    blk_sid.resize(pl.n_blocks);
+    for (uint32_t i = 0; i < n; ++i)
+      for (uint32_t b = pl.blk_base[i]; b < pl.blk_base[i + 1]; ++b) blk_sid[b] = i;
+    if ((rc = ensure(c, c->d_blk_sid, (size_t)pl.n_blocks * 4 + 4))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->d_blk_sid.p, blk_sid.data(), (size_t)pl.n_blocks * 4, hipMemcpyHostToDevice,
+                              c->stream));
+  }
 
   // Overlap (see flate_hip_ctx::overlap_sub): possible when the match finder is ONE persistent
   // resident+guest launch whose queue is the stream order (every stream has LZ77 chunks and all are
@@ -676,6 +699,7 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
   H.n_streams = n;
   H.compat_go = (flags & FLATE_HIP_COMPAT_GO) ? 1u : 0u;
   H.sid0 = 0;
+  H.blk_sid = per_block ? (const uint32_t *)c->d_blk_sid.p : nullptr;
   CompactParams C{};
   C.out_len = (const uint64_t *)c->d_out_len.p;
   C.out_off = (uint64_t *)c->d_out_off.p;
@@ -710,7 +734,10 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
     (void)hipStreamWaitEvent(c->stream, c->ev_ent, 0);
   } else {
     StageTimer t(c, FLATE_HIP_STAGE_HUFF_PACK);
-    hipLaunchKernelGGL(huff_hist_kernel, dim3(n), dim3(64), 0, c->stream, H);
+    if (per_block)
+      hipLaunchKernelGGL(huff_hist_block_kernel, dim3(pl.n_blocks), dim3(64), 0, c->stream, H);
+    else
+      hipLaunchKernelGGL(huff_hist_kernel, dim3(n), dim3(64), 0, c->stream, H);
     hipLaunchKernelGGL(huff_code_kernel, dim3(n), dim3(64), 0, c->stream, H);
     if (!spliced) {
       hipLaunchKernelGGL(scan_sizes_kernel, dim3(1), dim3(1024), 0, c->stream, C);
@@ -725,7 +752,13 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
       hipLaunchKernelGGL(splice_scan_kernel, dim3(1), dim3(1024), 0, c->stream, S);
       hipLaunchKernelGGL(splice_zero_kernel, dim3(n / 256 + 1), dim3(256), 0, c->stream, S, d_out);
     }
-    hipLaunchKernelGGL(huff_pack_kernel, dim3(n), dim3(64), 0, c->stream, H);
+    if (per_block) {
+      hipLaunchKernelGGL(huff_zero_edges_kernel, dim3(pl.n_blocks / 256 + 1), dim3(256), 0, c->stream, H,
+                         pl.n_blocks);
+      hipLaunchKernelGGL(huff_pack_block_kernel, dim3(pl.n_blocks), dim3(64), 0, c->stream, H);
+    } else {
+      hipLaunchKernelGGL(huff_pack_kernel, dim3(n), dim3(64), 0, c->stream, H);
+    }
   }
   HIP_TRY(c, hipGetLastError());
 

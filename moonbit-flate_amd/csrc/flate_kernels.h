@@ -87,6 +87,7 @@ struct HuffParams {
   uint32_t n_streams;
   uint32_t compat_go;
   uint32_t sid0;  // first stream of this launch (sub-batched launches; block b handles sid0 + b)
+  const uint32_t *blk_sid;  // per-block launches (huff_*_block_kernel): stream of every block, else null
   uint32_t no_close;  // spliced mode: the batch's last stream does not write Writer::close's block
                       // (a stream that continues in a later call: flate_hip_stream_write)
 };
@@ -135,6 +136,10 @@ __global__ void lz77_resume_kernel(LzParams P, uint16_t *table_io, uint32_t *clo
 __global__ void huff_hist_kernel(HuffParams P);
 __global__ void huff_code_kernel(HuffParams P);
 __global__ void huff_pack_kernel(HuffParams P);
+// one wavefront per block instead of per stream (multi-window streams)
+__global__ void huff_hist_block_kernel(HuffParams P);
+__global__ void huff_zero_edges_kernel(HuffParams P, uint32_t n_blocks);
+__global__ void huff_pack_block_kernel(HuffParams P);
 __global__ void uq_init_kernel(uint32_t *ready, uint32_t *ctr, uint32_t n_streams, uint32_t n_units);
 __global__ void scan_sizes_kernel(CompactParams P);
 // spins (bounded) until *counter >= target: gates a sub-batch of the entropy stage on the match

@@ -122,12 +122,14 @@ struct BitSink {
   uint32_t head;     // bytes of dword 0 that belong to the previous stream (0..3)
   uint32_t last_dw;  // dword holding the stream's last byte
   uint32_t tail;     // bytes of last_dw that belong to this stream (1..4)
-  bool bit_edges;    // spliced mode: dword 0 and last_dw are shared with the neighbouring streams
-                     // at bit granularity and OR-ed atomically into the zeroed destination
+  // dword 0 / last_dw shared at BIT granularity with what is written in front of / behind this sink
+  // (the neighbouring streams of a spliced batch; the neighbouring blocks of the same stream when
+  // every block has its own wavefront): OR-ed atomically into a destination zeroed beforehand
+  bool or_first, or_last;
 };
 
 FLATE_D void sink_store(const BitSink &S, uint32_t idx, uint32_t v) {
-  if (S.bit_edges && (idx == 0 || idx == S.last_dw)) {
+  if ((S.or_first && idx == 0) || (S.or_last && idx == S.last_dw)) {
     if (v) atomicOr(&S.out32[idx], v);
     return;
   }
@@ -690,13 +692,8 @@ FLATE_D uint32_t off_extra_of_code(uint32_t c) { return c < 4 ? 0u : (c >> 1) - 
 // block policy (deflate.mbt:243-269): kind 0 = stored (<= 16 B tail), 1 = Huffman-only,
 // 2 = dynamic.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void huff_hist_kernel(HuffParams P) {
-  __shared__ SharedHist sh;
-  const int lane = threadIdx.x;
-  const uint32_t sid = blockIdx.x + P.sid0;
-  if (sid >= P.n_streams) return;
-  const BlockGeom g = block_geom(P, sid);
-  for (uint32_t b = 0; b < g.nblocks; ++b) {
+// index_tokens / histogram of ONE block (and the enc_speed policy that picks its kind).
+FLATE_D void hist_block(const HuffParams &P, SharedHist &sh, const BlockGeom &g, uint32_t b, int lane) {
     const uint8_t *src = g.stream + (uint64_t)b * kMaxStoreBlockSize;
     const int n = b < g.full ? kMaxStoreBlockSize : g.r;
     const uint32_t gb = g.blk0 + b;
@@ -707,7 +704,7 @@ __global__ __launch_bounds__(64) void huff_hist_kernel(HuffParams P) {
       kind = P.chunk_ntok[g.chunk0 + b] > (uint32_t)(n - (n >> 4)) ? 1 : 2;  // deflate.mbt:266
     }
     if (lane == 0) P.blk_meta[gb] = make_uint4((uint32_t)kind, 0u, 0u, 0u);
-    if (kind == 0) continue;
+    if (kind == 0) return;
     for (int i = lane; i < 288; i += 64) sh.lit_freq[i] = 0;
     if (lane < 32) sh.off_freq[lane] = 0;
     // (four copies of the histograms at an odd stride, one per 16 lanes, were slower: 0.91 vs 0.84 ms)
@@ -754,6 +751,25 @@ __global__ __launch_bounds__(64) void huff_hist_kernel(HuffParams P) {
     if (lane < 32) h[288 + lane] = sh.off_freq[lane];
     __syncthreads();
   }
+
+__global__ __launch_bounds__(64) void huff_hist_kernel(HuffParams P) {
+  __shared__ SharedHist sh;
+  const int lane = threadIdx.x;
+  const uint32_t sid = blockIdx.x + P.sid0;
+  if (sid >= P.n_streams) return;
+  const BlockGeom g = block_geom(P, sid);
+  for (uint32_t b = 0; b < g.nblocks; ++b) hist_block(P, sh, g, b, lane);
+}
+
+// The same with one wavefront per BLOCK (multi-window streams: a batch of few long streams has few
+// wavefronts per stream-kernel; blk_sid maps a global block index to its stream).
+__global__ __launch_bounds__(64) void huff_hist_block_kernel(HuffParams P) {
+  __shared__ SharedHist sh;
+  const int lane = threadIdx.x;
+  const uint32_t gb = blockIdx.x;
+  const uint32_t sid = P.blk_sid[gb];
+  const BlockGeom g = block_geom(P, sid);
+  hist_block(P, sh, g, gb - g.blk0, lane);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -859,54 +875,8 @@ __global__ __launch_bounds__(64) void huff_code_kernel(HuffParams P) {
   }
 }
 
-// ---------------------------------------------------------------------------------------
-// write_dynamic_header (:421-471), write_tokens (:596-731), write_block_huff's byte loop
-// (:788-823), stored blocks: the stream's bits go to out + out_off[sid].
-// ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void huff_pack_kernel(HuffParams P) {
-  __shared__ SharedPack sh;
-  const int lane = threadIdx.x;
-  const uint32_t sid = blockIdx.x + P.sid0;
-  if (sid >= P.n_streams || *P.status != 0) return;
-  const BlockGeom g = block_geom(P, sid);
-
-  for (int i = lane; i < kRing; i += 64) sh.ring[i] = 0;
-  __syncthreads();
-  BitSink S;
-  S.ring = sh.ring;
-  S.flushed = 0;
-  S.bit_edges = P.spliced != 0;
-  uint64_t out_bits;  // what this stream must write
-  if (!P.spliced) {
-    uint8_t *dst = P.out + P.out_off[sid];
-    const uint64_t out_bytes = P.out_len[sid];
-    out_bits = 8 * out_bytes;
-    S.head = (uint32_t)((uintptr_t)dst & 3u);
-    S.out32 = reinterpret_cast<uint32_t *>(dst - S.head);
-    S.bitpos = 8ull * S.head;
-    const uint64_t end_byte = S.head + out_bytes;  // exclusive, relative to out32
-    S.last_dw = (uint32_t)((end_byte - 1) >> 2);
-    S.tail = (uint32_t)(((end_byte - 1) & 3u) + 1u);
-  } else {
-    // one DEFLATE stream for the whole batch (splice_kernels.hip): this stream's blocks start at
-    // bit stream_bit[sid] of the output; only the last stream writes the closing block.  The
-    // sink's bit position is congruent to the position in the spliced stream mod 8, so the
-    // padding of stored blocks comes out relative to the spliced stream.
-    const uint64_t mis = (uint64_t)((uintptr_t)P.out & 3u);
-    const uint64_t g0 = P.stream_bit[sid] + 8 * mis;  // relative to the aligned dword grid of out
-    uint64_t g1 = P.stream_bit[sid + 1] + 8 * mis;
-    const bool last_stream = sid + 1 == P.n_streams && !P.no_close;
-    if (last_stream) g1 = ((g1 + 3 + 7) & ~7ull) + 32;  // + closing block
-    out_bits = g1 - g0;
-    S.head = 0;
-    S.out32 = reinterpret_cast<uint32_t *>(P.out - mis) + (g0 >> 5);
-    S.bitpos = g0 & 31u;
-    S.last_dw = g1 > g0 ? (uint32_t)(((g1 - 1) >> 5) - (g0 >> 5)) : 0u;
-    S.tail = 4;  // (the batch's very last dword may reach 3 bytes past the result: out_cap covers it)
-  }
-  const uint64_t bit0 = S.bitpos;
-
-  for (uint32_t b = 0; b < g.nblocks; ++b) {
+// One block (write_block_dynamic / write_block_huff / a stored block) appended to the sink.
+FLATE_D void pack_block(const HuffParams &P, SharedPack &sh, BitSink &S, const BlockGeom &g, uint32_t b, int lane) {
     const uint8_t *src = g.stream + (uint64_t)b * kMaxStoreBlockSize;
     const int n = b < g.full ? kMaxStoreBlockSize : g.r;
     const uint32_t gb = g.blk0 + b;
@@ -914,7 +884,7 @@ __global__ __launch_bounds__(64) void huff_pack_kernel(HuffParams P) {
     const int kind = (int)meta.x;
     if (kind == 0) {
       emit_stored(S, src, n, false, lane);
-      continue;
+      return;
     }
     __syncthreads();
     const uint32_t *cl = P.blk_cl + (uint64_t)gb * kBlkStride;
@@ -1008,11 +978,155 @@ __global__ __launch_bounds__(64) void huff_pack_kernel(HuffParams P) {
     const uint32_t eob = sh.lit_cl[kEndBlockMarker];
     sink_emit(S, eob & 0xffffu, lane == 0 ? (eob >> 16) : 0u, lane);
   }
+
+// ---------------------------------------------------------------------------------------
+// write_dynamic_header (:421-471), write_tokens (:596-731), write_block_huff's byte loop
+// (:788-823), stored blocks: the stream's bits go to out + out_off[sid].
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void huff_pack_kernel(HuffParams P) {
+  __shared__ SharedPack sh;
+  const int lane = threadIdx.x;
+  const uint32_t sid = blockIdx.x + P.sid0;
+  if (sid >= P.n_streams || *P.status != 0) return;
+  const BlockGeom g = block_geom(P, sid);
+
+  for (int i = lane; i < kRing; i += 64) sh.ring[i] = 0;
+  __syncthreads();
+  BitSink S;
+  S.ring = sh.ring;
+  S.flushed = 0;
+  S.or_first = S.or_last = P.spliced != 0;
+  uint64_t out_bits;  // what this stream must write
+  if (!P.spliced) {
+    uint8_t *dst = P.out + P.out_off[sid];
+    const uint64_t out_bytes = P.out_len[sid];
+    out_bits = 8 * out_bytes;
+    S.head = (uint32_t)((uintptr_t)dst & 3u);
+    S.out32 = reinterpret_cast<uint32_t *>(dst - S.head);
+    S.bitpos = 8ull * S.head;
+    const uint64_t end_byte = S.head + out_bytes;  // exclusive, relative to out32
+    S.last_dw = (uint32_t)((end_byte - 1) >> 2);
+    S.tail = (uint32_t)(((end_byte - 1) & 3u) + 1u);
+  } else {
+    // one DEFLATE stream for the whole batch (splice_kernels.hip): this stream's blocks start at
+    // bit stream_bit[sid] of the output; only the last stream writes the closing block.  The
+    // sink's bit position is congruent to the position in the spliced stream mod 8, so the
+    // padding of stored blocks comes out relative to the spliced stream.
+    const uint64_t mis = (uint64_t)((uintptr_t)P.out & 3u);
+    const uint64_t g0 = P.stream_bit[sid] + 8 * mis;  // relative to the aligned dword grid of out
+    uint64_t g1 = P.stream_bit[sid + 1] + 8 * mis;
+    const bool last_stream = sid + 1 == P.n_streams && !P.no_close;
+    if (last_stream) g1 = ((g1 + 3 + 7) & ~7ull) + 32;  // + closing block
+    out_bits = g1 - g0;
+    S.head = 0;
+    S.out32 = reinterpret_cast<uint32_t *>(P.out - mis) + (g0 >> 5);
+    S.bitpos = g0 & 31u;
+    S.last_dw = g1 > g0 ? (uint32_t)(((g1 - 1) >> 5) - (g0 >> 5)) : 0u;
+    S.tail = 4;  // (the batch's very last dword may reach 3 bytes past the result: out_cap covers it)
+  }
+  const uint64_t bit0 = S.bitpos;
+
+  for (uint32_t b = 0; b < g.nblocks; ++b) pack_block(P, sh, S, g, b, lane);
   if (!P.spliced || (sid + 1 == P.n_streams && !P.no_close))
     emit_stored(S, g.stream, 0, true, lane);  // Compressor::close (deflate.mbt:171-176)
   sink_finish(S, lane);
   // the sizes computed by huff_code_kernel and the bits actually written must agree
   if (lane == 0 && S.bitpos - bit0 != out_bits) atomicExch(P.status, -(int)(0x100000u + (sid & 0xfffffu)));  // E_INTERNAL + stream
+}
+
+// ---------------------------------------------------------------------------------------
+// One wavefront per BLOCK (multi-window streams).  The blocks of a stream follow one another at bit
+// granularity, so the dword two of them share is zeroed first (huff_zero_edges_kernel, own bytes
+// only) and OR-ed into by both; the stream's first and last dword are shared with OTHER streams at
+// byte granularity (plain byte stores, as in huff_pack_kernel).  Batch form only: in a spliced batch
+// the bit a block starts at depends on where its stream starts (stored blocks pad to a byte of the
+// spliced stream), which the per-stream kernel finds as it walks.
+// ---------------------------------------------------------------------------------------
+namespace {
+struct StreamSpan {
+  uint32_t *origin;  // dword grid the stream's bit positions are counted on
+  uint64_t g0, g1;   // first bit of the stream's first block, end of the stream (closing block included)
+  uint32_t head;     // non-spliced: bytes of the first dword that belong to the previous stream
+};
+FLATE_D StreamSpan stream_span(const HuffParams &P, uint32_t sid) {
+  StreamSpan sp;
+  if (!P.spliced) {
+    uint8_t *dst = P.out + P.out_off[sid];
+    sp.head = (uint32_t)((uintptr_t)dst & 3u);
+    sp.origin = reinterpret_cast<uint32_t *>(dst - sp.head);
+    sp.g0 = 8ull * sp.head;
+    sp.g1 = sp.g0 + 8ull * P.out_len[sid];
+  } else {
+    const uint64_t mis = (uint64_t)((uintptr_t)P.out & 3u);
+    sp.head = 0;
+    sp.origin = reinterpret_cast<uint32_t *>(P.out - mis);
+    sp.g0 = P.stream_bit[sid] + 8 * mis;
+    sp.g1 = P.stream_bit[sid + 1] + 8 * mis;
+    if (sid + 1 == P.n_streams && !P.no_close) sp.g1 = ((sp.g1 + 3 + 7) & ~7ull) + 32;  // + closing block
+  }
+  return sp;
+}
+FLATE_D uint64_t block_start_bit(const HuffParams &P, uint32_t gb) {
+  const uint4 m = P.blk_meta[gb];
+  return (uint64_t)m.z | ((uint64_t)m.w << 32);
+}
+}  // namespace
+
+// One thread per block: the dword that holds a block's first bit, and the one in front of it, are
+// shared with the previous block of the same stream.
+__global__ __launch_bounds__(256) void huff_zero_edges_kernel(HuffParams P, uint32_t n_blocks) {
+  const uint32_t gb = blockIdx.x * 256u + threadIdx.x;
+  if (gb >= n_blocks || *P.status != 0) return;
+  const uint32_t sid = P.blk_sid[gb];
+  if (gb == P.blk_base[sid]) return;  // the stream's first block starts the stream
+  const StreamSpan sp = stream_span(P, sid);
+  const uint64_t x = sp.g0 + block_start_bit(P, gb);
+  uint8_t *bytes = reinterpret_cast<uint8_t *>(sp.origin);
+  // own bytes only: the stream's first and last dword may hold bytes of its neighbours
+  const uint64_t own_lo = P.spliced ? 0ull : sp.g0 >> 3, own_hi = P.spliced ? ~0ull : sp.g1 >> 3;
+  const uint64_t d = x >> 5;
+  for (uint64_t k = (d ? d - 1 : 0) * 4; k < (d + 1) * 4; ++k)
+    if (k >= own_lo && k < own_hi) bytes[k] = 0;
+}
+
+__global__ __launch_bounds__(64) void huff_pack_block_kernel(HuffParams P) {
+  __shared__ SharedPack sh;
+  const int lane = threadIdx.x;
+  const uint32_t gb = blockIdx.x;
+  if (*P.status != 0) return;
+  const uint32_t sid = P.blk_sid[gb];
+  const BlockGeom g = block_geom(P, sid);
+  const uint32_t b = gb - g.blk0;
+  const bool last = b + 1 == g.nblocks;
+  const StreamSpan sp = stream_span(P, sid);
+  const uint64_t x0 = sp.g0 + block_start_bit(P, gb);
+  const uint64_t x1 = last ? sp.g1 : sp.g0 + block_start_bit(P, gb + 1);
+
+  for (int i = lane; i < kRing; i += 64) sh.ring[i] = 0;
+  __syncthreads();
+  BitSink S;
+  S.ring = sh.ring;
+  S.flushed = 0;
+  S.out32 = sp.origin + (x0 >> 5);
+  S.bitpos = x0 & 31u;
+  S.last_dw = x1 > x0 ? (uint32_t)(((x1 - 1) >> 5) - (x0 >> 5)) : 0u;
+  S.head = (b == 0 && !P.spliced) ? sp.head : 0u;
+  S.tail = (last && !P.spliced) ? (uint32_t)((((x1 >> 3) - 1) & 3u) + 1u) : 4u;
+  S.or_first = b > 0 || P.spliced != 0;
+  S.or_last = !last || P.spliced != 0;
+  const uint64_t bit0 = S.bitpos;
+
+  pack_block(P, sh, S, g, b, lane);
+  if (last && (!P.spliced || (sid + 1 == P.n_streams && !P.no_close)))
+    emit_stored(S, g.stream, 0, true, lane);  // Compressor::close (deflate.mbt:171-176)
+  sink_finish(S, lane);
+#ifdef FLATE_PB_DEBUG
+  if (lane == 0 && S.bitpos - bit0 != x1 - x0)
+    printf("pb mismatch sid %u b %u/%u kind %u wrote %llu want %llu x0 %llu x1 %llu g0 %llu g1 %llu\n", sid, b, g.nblocks,
+           P.blk_meta[gb].x, (unsigned long long)(S.bitpos - bit0), (unsigned long long)(x1 - x0), (unsigned long long)x0,
+           (unsigned long long)x1, (unsigned long long)sp.g0, (unsigned long long)sp.g1);
+#endif
+  if (lane == 0 && S.bitpos - bit0 != x1 - x0) atomicExch(P.status, -(int)(0x100000u + (sid & 0xfffffu)));
 }
 
 }  // namespace flate

@@ -349,3 +349,40 @@ def test_host_pointer_pipeline_uneven_streams_three_groups(oracle):
         assert (st == 0).all() and np.array_equal(np.asarray(back)[:int(boff[-1])], host[:int(off[-1])])
     finally:
         e.close()
+
+
+def test_entropy_stage_with_one_wavefront_per_block(oracle):
+    # option "entropy_per_block": histogram and pack kernels run per BLOCK (multi-window streams); the
+    # blocks of a stream then meet at bit granularity inside shared dwords.  Same bytes as the oracle in
+    # the batch form (the spliced form keeps the per-stream kernels: same bytes there too), both compat modes, stored / Huffman-only / dynamic blocks,
+    # tails of every kind behind full windows.
+    specs = [("text", 4 * 65535 + t) for t in (0, 1, 16, 17, 127, 128, 5000)] + \
+            [("rand", 2 * 65535 + 9), ("zero", 3 * 65535), ("runs", 65535 + 40), ("low", 65536), ("text", 5),
+             ("period", 200000), ("text", 65535), ("rand", 17), ("ramp", 131070)]
+    data, off = make_streams(specs, seed=21)
+    e = flate.FlateEngine(0)
+    try:
+        e.set_option("entropy_per_block", 1)
+        for go in (False, True):
+            out, ooff = e.deflate_batch(data, off, compat_go=go)
+            for i in range(len(specs)):
+                want = oracle.deflate(data[int(off[i]):int(off[i + 1])], compat=oracle.COMPAT_GO if go else 0)
+                assert bytes(out[int(ooff[i]):int(ooff[i + 1])]) == want, (go, i, specs[i])
+            one, nb, bit_off = e.deflate_spliced(data, off, compat_go=go)
+            ref, ref_off = oracle.deflate_spliced(data, off, oracle.COMPAT_GO if go else 0)
+            assert bytes(one[:nb]) == ref and (bit_off == ref_off).all(), go
+        # a misaligned output buffer (streams start at every byte offset inside a dword)
+        import torch
+        d = torch.from_numpy(data).cuda()
+        out, ooff = e.deflate_batch(data, off)
+        buf = torch.zeros(int(ooff[-1]) + 64, dtype=torch.uint8, device="cuda")
+        for mis in (1, 2, 3):
+            o2, oo2 = e.deflate_batch(d, off, out=buf[mis:])
+            assert np.array_equal(oo2, ooff) and bytes(o2[:int(oo2[-1])].cpu().numpy()) == bytes(out[:int(ooff[-1])]), mis
+        # an empty stream in the batch: the per-stream kernels take over, same bytes
+        data2, off2 = make_streams(specs[:3] + [("text", 0)] + specs[3:6], seed=22)
+        out2, ooff2 = e.deflate_batch(data2, off2)
+        for i in range(7):
+            assert bytes(out2[int(ooff2[i]):int(ooff2[i + 1])]) == oracle.deflate(data2[int(off2[i]):int(off2[i + 1])]), i
+    finally:
+        e.close()

@@ -27,7 +27,11 @@ while time.time() - t0 < budget:
     eng.set_option("guest_min_streams", 1 if guests else 1 << 30)
     eng.set_option("guest_blocks", int(rng.choice([8, 64, 256])) if guests else 0)
     eng.set_option("overlap_sub_batches", int(rng.choice([0, 0, 2, 8])))  # (only takes effect on uniform batches)
+    eng.set_option("entropy_per_block", int(rng.choice([-1, 0, 1, 1])))   # (1: one wavefront per block where possible)
     cm = O.COMPAT_GO if go else O.COMPAT_MOONBIT
+    if rng.random() < 0.3:  # some rounds without empty streams, so that the per-block entropy kernels really run
+        specs = [(k, max(sz, 1)) for k, sz in specs]
+        data, off = make_streams(specs, seed=seed)
     tag = "seed=%d go=%s guests=%s n=%d" % (seed, go, guests, n)
     out, ooff = eng.deflate_batch(data, off, compat_go=go)
     ref, roff, rlen = O.deflate_batch(data, off, compat=cm, nthreads=8)
