@@ -65,10 +65,11 @@ struct flate_hip_ctx {
   // the speculative wave-per-stream decoder (inflate_spec_kernel): 0 = never, 1 = for batches below
   // inflate_spec_max streams (where it beats both other decoders), 2 = always (tests)
   int inflate_spec = 1;
-  uint32_t inflate_spec_max = 18432;  // measured (tools/inflate_crossover.py, ms per batch of 64 KiB streams):
-                                      // 1024 streams 4.6 against 13.7 (wave per stream) and 27 (lane per
-                                      // stream); 4096: 9.3 / 52 / 25; 8192: 14.7 / - / 26; 16384: 26.1 / - / 29.2;
-                                      // 32768: 49 / - / 30.5 -- the lane-per-stream decoder wins from ~18 k streams on
+  int inflate_spec_shape = 0;  // 0 = by batch size, 1 / 2 = always the small-batch / large-batch build (tests, tuning)
+  uint32_t inflate_spec_max = 28672;  // measured (tools/inflate_crossover.py, ms per batch of 64 KiB text streams):
+                                      // 1024 streams 1.9 against 13.7 (wave per stream) and 27 (lane per
+                                      // stream); 4096: 4.3 / 52 / 25; 16384: 16.4 / - / 29.1; 32768: 32.2 / - / 30.5
+                                      // -- the lane-per-stream decoder wins from ~30 k streams on
   uint32_t resident_blocks = 1024;  // persistent LDS-table blocks (4 per CU x 256 CUs)
   // Entropy stage overlapped with the match finder: the batch is cut into overlap_sub sub-batches
   // (queue order); hist/code/scan/pack of a sub-batch run on ent_stream as soon as the match finder
@@ -526,6 +527,8 @@ int flate_hip_set_option(flate_hip_ctx *c, const char *name, int64_t value) {
     c->inflate_simt_min = (uint32_t)value;
   } else if (k == "inflate_spec" && value >= 0 && value <= 2) {
     c->inflate_spec = (int)value;
+  } else if (k == "inflate_spec_shape" && value >= 0 && value <= 2) {
+    c->inflate_spec_shape = (int)value;
   } else if (k == "inflate_spec_max_streams" && value >= 0 && value <= 0x7fffffff) {
     c->inflate_spec_max = (uint32_t)value;
   } else if (k == "resident_blocks" && value > 0 && value <= 65536) {
@@ -1332,7 +1335,13 @@ static int inflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
     bool spec = !spliced && !size_only && (c->inflate_spec == 2 || (c->inflate_spec == 1 && n < c->inflate_spec_max));
     for (uint32_t i = 0; i < n && spec; ++i) spec = in_off[i + 1] - in_off[i] < (1ull << 28);  // 32-bit bit positions
     if (spec) {
-      hipLaunchKernelGGL(inflate_spec_kernel, dim3(n), dim3(64), 0, c->stream, I);
+      // (two builds of the same kernel: long token lists and a 16 KiB history ring while a SIMD holds
+      // one wavefront, the small footprint beyond)
+      const int shape = c->inflate_spec_shape ? c->inflate_spec_shape : (n <= 4u * c->num_cus ? 1 : 2);
+      if (shape == 1)
+        hipLaunchKernelGGL(inflate_spec_kernel<FLATE_SPEC_SMALL>, dim3(n), dim3(64), 0, c->stream, I);
+      else
+        hipLaunchKernelGGL(inflate_spec_kernel<FLATE_SPEC_LARGE>, dim3(n), dim3(64), 0, c->stream, I);
     } else if (simt) {
       // streams per wavefront: as many as still leave four wavefronts (one per SIMD) per CU
       int lpw = c->inflate_lanes;

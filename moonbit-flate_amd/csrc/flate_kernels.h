@@ -146,7 +146,16 @@ __global__ void scan_sizes_kernel(CompactParams P);
 // finder that is still running on another stream
 __global__ void wait_count_kernel(const uint32_t *counter, uint32_t target, int *status, uint32_t spin_limit);
 __global__ void inflate_kernel(InfParams P);
-__global__ void inflate_spec_kernel(InfParams P);  // one wavefront per stream, 64 token starts decoded at once
+// one wavefront per stream, 64 sub-blocks of the bit stream decoded at once (inflate_spec_kernel.inc):
+// <bits per sub-block, tokens per list, bytes of history ring>
+template <int SUB, int CAP, int RING>
+__global__ void inflate_spec_kernel(InfParams P);
+#ifndef FLATE_SPEC_SMALL
+#define FLATE_SPEC_SMALL 288, 57, 16384  // batches up to one wavefront per SIMD
+#endif
+#ifndef FLATE_SPEC_LARGE
+#define FLATE_SPEC_LARGE 224, 45, 2048  // 19.4 KiB of LDS: two wavefronts per SIMD
+#endif
 template <int LPW>
 __global__ void inflate_simt_kernel(InfParams P);
 

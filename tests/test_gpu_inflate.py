@@ -9,13 +9,15 @@ from util import flate, make_streams
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["wave_per_stream", "lane_per_stream", "speculative_wave"])
+@pytest.fixture(scope="module", params=["wave_per_stream", "lane_per_stream", "speculative_wave_small_batch",
+                                        "speculative_wave_large_batch"])
 def eng(request):
-    """All three inflater kernels must pass every test: the options force one of them."""
+    """All three inflater kernels (both builds of the third) must pass every test: the options force one of them."""
     flate.build()
     e = flate.FlateEngine(0)
     e.set_option("inflate_simt_min_streams", 0 if request.param == "lane_per_stream" else 1 << 30)
-    e.set_option("inflate_spec", 2 if request.param == "speculative_wave" else 0)
+    e.set_option("inflate_spec", 2 if request.param.startswith("speculative_wave") else 0)
+    e.set_option("inflate_spec_shape", 1 if request.param.endswith("small_batch") else 2)
     yield e
     e.close()
 

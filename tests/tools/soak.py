@@ -47,6 +47,7 @@ while time.time() - t0 < budget:
     for simt_min, spec in ((0, 0), (1 << 30, 0), (1 << 30, 2)):  # lane per stream, wave per stream, speculative wave
         eng.set_option("inflate_simt_min_streams", simt_min)
         eng.set_option("inflate_spec", spec)
+        eng.set_option("inflate_spec_shape", int(rng.choice([0, 1, 2])))
         eng.set_option("inflate_lanes", int(rng.choice([0, 16, 32, 64])))
         back, _, olen, status, _ = eng.inflate_batch(comp, ooff, szs)
         assert (status == 0).all() and list(olen) == szs, "inflate status (%s)" % tag
