@@ -573,8 +573,8 @@ def bench_inflate(args, env, d_in, in_off, n, blen, host=None, steps=None, warmu
     k_ms = ms / steps
     achieved = (n * blen + clen) / (k_ms * 1e-3) / 1e9
     traffic, traffic_src = None, None
-    if args.kind == "text" and blen == 65536 and n == 131072 and not args.spliced:
-        traffic, traffic_src = pmc_traffic("inflate_traffic.json", "inflate_131072x65536_text", env["flate"], args,
+    if args.kind == "text" and blen == 65536 and n in (131072, 16384) and not args.spliced:
+        traffic, traffic_src = pmc_traffic("inflate_traffic.json", "inflate_%dx65536_text" % n, env["flate"], args,
                                            group="inflate")
     return {
         "metric": "GiB/s decompressed output (inflate), 64 KiB streams", "unit": "GiB/s",
@@ -586,7 +586,8 @@ def bench_inflate(args, env, d_in, in_off, n, blen, host=None, steps=None, warmu
                                % ("ONE spliced stream of " if args.spliced else "", n, blen, args.kind),
                    "compressed_bytes_per_gpu": clen,
                    "stage_ms": {"inflate": round(k_ms, 3)}, "step_ms": summarize(step_s)},
-        "roofline": {"bound": "hbm", "kernel": "inflate_simt_kernel" if n > 2048 else "inflate_kernel",
+        # (the library's choice at its default options: the sub-block decoder below 28672 streams)
+        "roofline": {"bound": "hbm", "kernel": "inflate_simt_kernel" if (args.spliced or n >= 28672) else "inflate_spec_kernel",
                      "achieved": round(achieved, 2),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                      "traffic": traffic, "traffic_source": traffic_src},
@@ -710,6 +711,13 @@ def extra_legs(args, env):
     extra["config5_inflate_8GiB"] = {k: r[k] for k in ("metric", "value", "unit", "steps", "ms_per_step",
                                                        "config", "roofline", "end_to_end_host_pointers")
                                      if k in r}
+    # ---- the headline batch's own output inflated again: 16384 streams = 1 GiB (one wavefront per
+    # stream, sub-block decoder)
+    n = 16384
+    ia.inflate_host_leg = False
+    r = bench_inflate(ia, env, d_in[:n * blen], in_off[:n + 1], n, blen, steps=5, warmup=2)
+    extra["inflate_1GiB_16384_streams"] = {k: r[k] for k in ("metric", "value", "unit", "steps", "ms_per_step",
+                                                             "config", "roofline") if k in r}
     return extra
 
 
