@@ -1328,11 +1328,12 @@ static int inflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
     // large batches: one lane per stream (64 streams per wavefront); small ones: one wavefront
     // per stream
     // (its bit positions are 32-bit: every compressed stream must be < 256 MiB)
-    // (size-only passes use the wave-per-stream decoder: its history is the LDS window, the
-    // lane-per-stream one reads its history back from the output it has written)
+    // (size-only passes never use the lane-per-stream decoder: it reads its history back from the
+    // output it has written)
     bool simt = (spliced || n >= c->inflate_simt_min) && !size_only;
     for (uint32_t i = 0; i < n && simt && !spliced; ++i) simt = in_off[i + 1] - in_off[i] < (1ull << 28);
-    bool spec = !spliced && !size_only && (c->inflate_spec == 2 || (c->inflate_spec == 1 && n < c->inflate_spec_max));
+    // (a size-only pass needs token lengths only: the sub-block decoder at any batch size, unless switched off)
+    bool spec = !spliced && (c->inflate_spec == 2 || (c->inflate_spec == 1 && (size_only || n < c->inflate_spec_max)));
     for (uint32_t i = 0; i < n && spec; ++i) spec = in_off[i + 1] - in_off[i] < (1ull << 28);  // 32-bit bit positions
     if (spec) {
       // (two builds of the same kernel: long token lists and a 16 KiB history ring while a SIMD holds

@@ -74,7 +74,16 @@ def test_sticky_rules(eng):
         w2._write(np.zeros(W, np.uint8), False)  # after close
 
 
-def test_size_only_pass_gives_the_exact_sizes(eng, oracle):
+@pytest.mark.parametrize("kernel", ["sub_block_decoder", "wave_per_stream"])
+def test_size_only_pass_gives_the_exact_sizes(eng, oracle, kernel):
+    eng.set_option("inflate_spec", 1 if kernel == "sub_block_decoder" else 0)
+    try:
+        _size_only_checks(eng, oracle)
+    finally:
+        eng.set_option("inflate_spec", 1)
+
+
+def _size_only_checks(eng, oracle):
     specs = [("text", 70000), ("zero", 300000), ("rand", 5000), ("low", 0), ("runs", 131070), ("text", 17)]
     data, off = make_streams(specs, seed=3)
     comp, coff = eng.deflate_batch(data, off)
