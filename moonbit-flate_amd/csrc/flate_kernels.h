@@ -154,7 +154,7 @@ __global__ void inflate_spec_kernel(InfParams P);
 #define FLATE_SPEC_SMALL 288, 57, 16384  // batches up to one wavefront per SIMD
 #endif
 #ifndef FLATE_SPEC_LARGE
-#define FLATE_SPEC_LARGE 224, 45, 2048  // 19.4 KiB of LDS: two wavefronts per SIMD
+#define FLATE_SPEC_LARGE 224, 49, 2048  // 19.9 KiB of LDS: two wavefronts per SIMD
 #endif
 template <int LPW>
 __global__ void inflate_simt_kernel(InfParams P);

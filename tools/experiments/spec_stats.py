@@ -11,6 +11,7 @@ off = flate.uniform_offsets(n, blen)
 comp, coff = eng.deflate_batch(d, off)
 eng.set_option("inflate_simt_min_streams", 1 << 30)
 eng.set_option("inflate_spec", 2)
+eng.set_option("inflate_spec_shape", int(os.environ.get("SHAPE", "0")))
 out = torch.empty(n * blen, dtype=torch.uint8, device="cuda")
 eng.inflate_batch(comp, coff, [blen] * n, out=out)
 torch.cuda.synchronize()

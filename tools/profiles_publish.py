@@ -16,6 +16,11 @@ for name, out in (("bench.json", pre + "_bench.json"), ("bench_under_rocprof.jso
     json.dump(last_json(os.path.join(src, name)), open(os.path.join(dst, out), "w"), indent=1)
 for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
     shutil.copy(f, os.path.join(dst, pre + "_kernel_stats.csv"))
+for f in glob.glob(os.path.join(src, "stats_inf16k", "**", "*kernel_stats.csv"), recursive=True):
+    shutil.copy(f, os.path.join(dst, pre + "_inflate16k_kernel_stats.csv"))
+if os.path.exists(os.path.join(src, "inflate16k_under_rocprof.json")):
+    json.dump(last_json(os.path.join(src, "inflate16k_under_rocprof.json")),
+              open(os.path.join(dst, pre + "_inflate16k_under_rocprof.json"), "w"), indent=1)
 for name, out in (("soak.txt", pre + "_soak.txt"), ("inflate_crossover.txt", "inflate_crossover.txt"),
                   ("gpu_tests.txt", pre + "_gpu_tests.txt")):
     if os.path.exists(os.path.join(src, name)):
