@@ -828,34 +828,61 @@ FLATE_D uint32_t uq_run(const LzParams &P, const UqUnit u, uint16_t *table, int 
   if (u.c != 0) {
     clock = (uint32_t)__builtin_amdgcn_readfirstlane(
         (int)__hip_atomic_load(P.uq_sweep + u.q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    for (int i = lane; i < kTableSize / 2; i += 64)
-      work[i] = __hip_atomic_load(home + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // The table arrives from another block (an LDS-table block keeps no tags, and a guest's tags stay
+    // behind in its LDS): a guest rebuilds its slot tags from the bytes the slots point at while the
+    // table passes through its registers.  A slot holds (position + 1) mod 2^16 of a position at
+    // most kMarkerBack behind this window's start W (older ones were swept to a marker, which is out
+    // of range for every lookup whatever its tag says).
+    const uint8_t *stream = P.in + P.in_off[sid];
+    const uint32_t W = u.c * (uint32_t)kMaxStoreBlockSize;
+    if (tags) {
+      for (int i = lane; i < kTableSize / 16; i += 64) tags[i] = 0;
+      __syncthreads();
+    }
+    // (sixteen loads in flight per lane: one at a time, each waited for before its store, was 128
+    // round trips through the fabric per window -- a tenth of the window's own time; the tags' gathers
+    // likewise, sixteen at a time)
+    static_assert(kTableSize / 2 % (64 * 16) == 0, "table = whole rounds of 16 dwords per lane");
+    for (int i0 = lane; i0 < kTableSize / 2; i0 += 64 * 16) {
+      uint32_t w[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) w[k] = __hip_atomic_load(home + i0 + 64 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) work[i0 + 64 * k] = w[k];
+      if (tags) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          uint32_t cv[16];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {  // dword half * 8 + j / 2, its low or high slot
+            const uint32_t slot = (w[half * 8 + j / 2] >> (16 * (j & 1))) & 0xffffu;
+            const uint32_t back = (W + 1u - slot) & 0xffffu;  // W - position
+            cv[j] = (back != 0u && back <= W) ? ld32(stream + (W - back)) : 0xffffffffu;
+          }
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const uint32_t slot = (w[half * 8 + j / 2] >> (16 * (j & 1))) & 0xffffu;
+            const uint32_t back = (W + 1u - slot) & 0xffffu;
+            const uint32_t h = 2u * (uint32_t)(i0 + 64 * (half * 8 + j / 2)) + (uint32_t)(j & 1);
+            if (back != 0u && back <= W) atomicOr(&tags[h >> 4], tag_of(cv[j]) << (2u * (h & 15u)));
+          }
+        }
+      }
+    }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
-  if (tags && u.c != 0) {
-    // The table has just arrived from another block (an LDS-table block keeps no tags, and a guest's
-    // tags stay behind in its LDS): rebuild the slot tags from the bytes the slots point at.  16384
-    // four-byte gathers, < 1 % of a window's time.  A slot holds (position + 1) mod 2^16 of a position
-    // at most kMarkerBack behind this window's start W (older ones were swept to a marker, which is
-    // out of range for every lookup whatever its tag says).
-    const uint64_t a0 = P.in_off[sid];
-    const uint8_t *stream = P.in + a0;
-    const uint32_t W = u.c * (uint32_t)kMaxStoreBlockSize;
-    for (int i = lane; i < kTableSize / 16; i += 64) tags[i] = 0;
-    __syncthreads();
-    for (int h = lane; h < kTableSize; h += 64) {
-      const uint32_t back = (W + 1u - (uint32_t)table[h]) & 0xffffu;  // W - position
-      if (back != 0u && back <= W) tag_set(tags, (uint32_t)h, tag_of(ld32(stream + (W - back))));
-    }
-    __syncthreads();
-  }
   lz77_stream<true, GUEST>(P, sid, table, lane, u.c, u.c + 1, &clock, tags);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
   if (u.c + 1 < nch) {
-    for (int i = lane; i < kTableSize / 2; i += 64)
-      __hip_atomic_store(home + i, work[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i0 = lane; i0 < kTableSize / 2; i0 += 64 * 16) {  // (a guest's working table is in memory too)
+      uint32_t w[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) w[k] = work[i0 + 64 * k];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) __hip_atomic_store(home + i0 + 64 * k, w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (lane == 0) __hip_atomic_store(P.uq_sweep + u.q, clock, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // every storing lane drains
     __syncthreads();
