@@ -96,6 +96,40 @@ def test_inflate_errors_match_oracle(eng, oracle):
             assert bytes(out[int(ooff[i]):int(ooff[i]) + int(olen[i])]) == res
 
 
+def test_inflate_errors_in_long_streams_match_oracle(eng, oracle):
+    """Corruptions anywhere in multi-block streams of a few hundred KB, and output slots that end
+    anywhere inside them: status, error offset and the bytes produced up to a corruption's block
+    are the oracle's (the sub-block decoder is many batches into the stream when it meets them)."""
+    rng = np.random.default_rng(77)
+    blobs, caps = [], []
+    for kind, n in (("text", 200000), ("low", 150000), ("period", 100000)):
+        one, _ = make_streams([(kind, n)], seed=n)
+        raw = bytes(one[:n])
+        good = oracle.deflate(raw)
+        for _ in range(12):
+            g = bytearray(good)
+            k = int(rng.integers(len(g) // 8, len(g)))
+            g[k] ^= int(rng.integers(1, 256))
+            blobs.append(bytes(g))
+            caps.append(n + 1000)
+        for _ in range(6):  # truncated input
+            blobs.append(good[:int(rng.integers(len(good) // 4, len(good) - 1))])
+            caps.append(n + 1000)
+        for _ in range(6):  # output slot too small
+            blobs.append(good)
+            caps.append(int(rng.integers(1, n)))
+    data, off = _pack(blobs)
+    out, ooff, olen, status, err = eng.inflate_batch(data, off, caps, check=False)
+    for i, bl in enumerate(blobs):
+        rc, res, used, eoff = oracle.inflate(bl, caps[i], full=True)
+        want_status = {0: 0, oracle.E_CORRUPT: -4, oracle.E_UNEXPECTED_EOF: -7,
+                       oracle.E_OUT_TOO_SMALL: -2}[rc]
+        assert int(status[i]) == want_status, (i, int(status[i]), rc)
+        assert int(err[i]) == eoff, (i, int(err[i]), eoff)
+        if rc == 0:
+            assert bytes(out[int(ooff[i]):int(ooff[i]) + int(olen[i])]) == res
+
+
 def test_inflate_output_too_small(eng, oracle):
     good = oracle.deflate(bytes(flate.synth("text", 1, 5000)))
     data, off = _pack([good])
