@@ -66,10 +66,10 @@ struct flate_hip_ctx {
   // inflate_spec_max streams (where it beats both other decoders), 2 = always (tests)
   int inflate_spec = 1;
   int inflate_spec_shape = 0;  // 0 = by batch size, 1 / 2 = always the small-batch / large-batch build (tests, tuning)
-  uint32_t inflate_spec_max = 28672;  // measured (tools/inflate_crossover.py, ms per batch of 64 KiB text streams):
-                                      // 1024 streams 1.9 against 13.7 (wave per stream) and 27 (lane per
-                                      // stream); 4096: 4.3 / 52 / 25; 16384: 16.4 / - / 29.1; 32768: 32.2 / - / 30.5
-                                      // -- the lane-per-stream decoder wins from ~30 k streams on
+  uint32_t inflate_spec_max = 36864;  // measured (tools/inflate_crossover.py, ms per batch of 64 KiB text streams):
+                                      // 1024 streams 1.7 against 13.7 (wave per stream) and 27 (lane per
+                                      // stream); 4096: 3.6 / 52 / 25; 16384: 13.8 / - / 29.1; 32768: 27.1 / - / 30.6;
+                                      // 40960: 33.8 / - / 31.9 -- the lane-per-stream decoder wins from ~37 k streams on
   uint32_t resident_blocks = 1024;  // persistent LDS-table blocks (4 per CU x 256 CUs)
   // Entropy stage overlapped with the match finder: the batch is cut into overlap_sub sub-batches
   // (queue order); hist/code/scan/pack of a sub-batch run on ent_stream as soon as the match finder
