@@ -1333,8 +1333,9 @@ static int inflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
     bool simt = (spliced || n >= c->inflate_simt_min) && !size_only;
     for (uint32_t i = 0; i < n && simt && !spliced; ++i) simt = in_off[i + 1] - in_off[i] < (1ull << 28);
     // (a size-only pass needs token lengths only: the sub-block decoder at any batch size, unless switched off)
-    bool spec = !spliced && (c->inflate_spec == 2 || (c->inflate_spec == 1 && (size_only || n < c->inflate_spec_max)));
-    for (uint32_t i = 0; i < n && spec; ++i) spec = in_off[i + 1] - in_off[i] < (1ull << 28);  // 32-bit bit positions
+    bool spec = c->inflate_spec == 2 || (c->inflate_spec == 1 && (size_only || n < c->inflate_spec_max));
+    // 32-bit bit positions: a stream (a piece of a spliced stream: in_off holds bit offsets then) below 256 MiB
+    for (uint32_t i = 0; i < n && spec; ++i) spec = in_off[i + 1] - in_off[i] < (spliced ? (1ull << 31) : (1ull << 28));
     if (spec) {
       // (two builds of the same kernel: long token lists and a 16 KiB history ring while a SIMD holds
       // one wavefront, the small footprint beyond)

@@ -114,7 +114,7 @@ struct InfParams {
   int32_t *status;
   int64_t *err_off;
   uint32_t n_streams;
-  // spliced input (inflate_simt_kernel only): the n_streams pieces of ONE DEFLATE stream in[0, in_len);
+  // spliced input (inflate_simt_kernel, inflate_spec_kernel): the n_streams pieces of ONE DEFLATE stream in[0, in_len);
   // piece i starts at bit bit_off[i] and ends where piece i+1 starts; the last one runs to BFINAL.
   // NULL: independent streams given by in_off.
   const uint64_t *bit_off;

@@ -15,6 +15,19 @@ SPECS = [("text", 65536), ("text", 0), ("ramp", 70000), ("rand", 300), ("text", 
          ("text", 16), ("runs", 40000), ("text", 127), ("text", 128)]
 
 
+def _inflaters(eng):
+    """The two kernels that decode a spliced stream from its index (and both builds of the second):
+    every inflate_spliced check runs on each."""
+    try:
+        for name, spec, shape in (("lane_per_stream", 0, 0), ("sub_block_small_batch", 2, 1), ("sub_block_large_batch", 2, 2)):
+            eng.set_option("inflate_spec", spec)
+            eng.set_option("inflate_spec_shape", shape)
+            yield name
+    finally:
+        eng.set_option("inflate_spec", 1)
+        eng.set_option("inflate_spec_shape", 0)
+
+
 def _inflate_one(stream):
     d = zlib.decompressobj(-15)
     res = d.decompress(stream) + d.flush()
@@ -158,10 +171,11 @@ def test_gpu_inflate_spliced_from_the_index(eng, oracle, compat):
     spliced, bit_off = oracle.deflate_spliced(data, off, oracle.COMPAT_GO if go else oracle.COMPAT_MOONBIT)
     sizes = [int(off[i + 1] - off[i]) for i in range(len(off) - 1)]
     comp = np.frombuffer(spliced + b"\0" * 8, dtype=np.uint8).copy()
-    out, ooff, olen, status, _ = eng.inflate_spliced(comp, len(spliced), bit_off, sizes)
-    assert (status == 0).all() and list(olen) == sizes
     whole = oracle.inflate(spliced, int(off[-1]))
-    assert bytes(out[:int(off[-1])]) == whole == data[:int(off[-1])].tobytes()
+    for kernel in _inflaters(eng):
+        out, ooff, olen, status, _ = eng.inflate_spliced(comp, len(spliced), bit_off, sizes)
+        assert (status == 0).all() and list(olen) == sizes, kernel
+        assert bytes(out[:int(off[-1])]) == whole == data[:int(off[-1])].tobytes(), kernel
 
 
 @pytest.mark.gpu
@@ -172,13 +186,14 @@ def test_gpu_inflate_spliced_bad_index_and_full_round_trip(eng, oracle):
     d_in = torch.from_numpy(host).cuda()
     in_off = flate.uniform_offsets(n, blen)
     comp, nbytes, bit_off = eng.deflate_spliced(d_in, in_off)
-    out, _, olen, status, _ = eng.inflate_spliced(comp, nbytes, bit_off, [blen] * n)
-    assert (status == 0).all() and (olen == blen).all() and torch.equal(out[:n * blen], d_in)
     bad = bit_off.copy()
     bad[7] += 1          # piece 6 now runs into piece 7's first block, piece 7 starts mid-block
-    _, _, _, status, _ = eng.inflate_spliced(comp, nbytes, bad, [blen] * n, check=False)
-    assert status[6] in (-2, -4) and status[7] != 0   # output overflow or off-boundary stop
-    assert (np.delete(status, [6, 7]) == 0).all()
+    for kernel in _inflaters(eng):
+        out, _, olen, status, _ = eng.inflate_spliced(comp, nbytes, bit_off, [blen] * n)
+        assert (status == 0).all() and (olen == blen).all() and torch.equal(out[:n * blen], d_in), kernel
+        _, _, _, status, _ = eng.inflate_spliced(comp, nbytes, bad, [blen] * n, check=False)
+        assert status[6] in (-2, -4) and status[7] != 0, kernel   # output overflow or off-boundary stop
+        assert (np.delete(status, [6, 7]) == 0).all(), kernel
 
 
 @pytest.mark.gpu
@@ -196,9 +211,10 @@ def test_gpu_spliced_fuzz_random_sizes(eng, oracle):
         ref, ref_off = oracle.deflate_spliced(data, off, oracle.COMPAT_GO if go else oracle.COMPAT_MOONBIT)
         assert bytes(out[:n]) == ref and np.array_equal(bit_off, ref_off), rnd
         sizes = [s for _, s in specs]
-        back, _, olen, status, _ = eng.inflate_spliced(out, n, bit_off, sizes)
-        assert (status == 0).all() and list(olen) == sizes
-        assert bytes(back[:int(off[-1])]) == data[:int(off[-1])].tobytes()
+        for kernel in _inflaters(eng):
+            back, _, olen, status, _ = eng.inflate_spliced(out, n, bit_off, sizes)
+            assert (status == 0).all() and list(olen) == sizes, kernel
+            assert bytes(back[:int(off[-1])]) == data[:int(off[-1])].tobytes(), kernel
 
 
 @pytest.mark.gpu
