@@ -130,6 +130,42 @@ def test_inflate_errors_in_long_streams_match_oracle(eng, oracle):
             assert bytes(out[int(ooff[i]):int(ooff[i]) + int(olen[i])]) == res
 
 
+def test_inflate_token_density_swings(eng, oracle):
+    """Streams whose token length changes abruptly -- text, then a run of zeros (258-byte matches of
+    two or three bits), then a four-symbol alphabet, then random bytes, and back: the sub-block
+    decoder's lists fill up and its sub-block size has to follow; encoders: ours, the oracle's, zlib."""
+    rng = np.random.default_rng(2024)
+    def piece(kind, n):
+        one, _ = make_streams([(kind, n)], seed=int(rng.integers(1 << 30)))
+        return bytes(one[:n])
+    plains = []
+    for _ in range(6):
+        parts = [piece(str(rng.choice(["text", "zero", "low", "rand", "runs", "ramp", "period"])),
+                       int(rng.choice([300, 3000, 20000, 70000]))) for _ in range(int(rng.integers(3, 9)))]
+        plains.append(b"".join(parts))
+    blobs, want = [], []
+    for p in plains:
+        blobs.append(oracle.deflate(p))
+        want.append(p)
+        for level in (1, 9):
+            co = zlib.compressobj(level, zlib.DEFLATED, -15)
+            blobs.append(co.compress(p) + co.flush())
+            want.append(p)
+    data, off = _pack(blobs)
+    out, ooff, olen, status, _ = eng.inflate_batch(data, off, [len(w) for w in want])
+    assert (status == 0).all() and list(olen) == [len(w) for w in want]
+    for i, w in enumerate(want):
+        assert bytes(out[int(ooff[i]):int(ooff[i]) + len(w)]) == w, i
+    # and through our own encoder (multi-window streams, both compat modes)
+    raw = np.frombuffer(b"".join(plains), dtype=np.uint8).copy()
+    roff = np.zeros(len(plains) + 1, np.uint64)
+    np.cumsum([len(p) for p in plains], out=roff[1:])
+    for go in (False, True):
+        comp, coff = eng.deflate_batch(raw, roff, compat_go=go)
+        back, boff, blen, st, _ = eng.inflate_batch(comp, coff, [len(p) for p in plains])
+        assert (st == 0).all() and bytes(back[:int(boff[-1])]) == raw.tobytes()
+
+
 def test_inflate_output_too_small(eng, oracle):
     good = oracle.deflate(bytes(flate.synth("text", 1, 5000)))
     data, off = _pack([good])
