@@ -151,10 +151,10 @@ __global__ void inflate_kernel(InfParams P);
 template <int SUB, int CAP, int RING>
 __global__ void inflate_spec_kernel(InfParams P);
 #ifndef FLATE_SPEC_SMALL
-#define FLATE_SPEC_SMALL 288, 57, 16384  // batches up to one wavefront per SIMD
+#define FLATE_SPEC_SMALL 288, 61, 8192  // batches up to one wavefront per SIMD (31.4 KiB of LDS)
 #endif
 #ifndef FLATE_SPEC_LARGE
-#define FLATE_SPEC_LARGE 224, 49, 2048  // 19.9 KiB of LDS: two wavefronts per SIMD
+#define FLATE_SPEC_LARGE 224, 47, 512  // 19.9 KiB of LDS: two wavefronts per SIMD
 #endif
 template <int LPW>
 __global__ void inflate_simt_kernel(InfParams P);
