@@ -216,12 +216,21 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
   auto sweep = [&](uint32_t R) {
     uint32_t *t32 = reinterpret_cast<uint32_t *>(table);
     const uint32_t marker = (R - kMarkerBack + 1u) & 0xffffu;
-    for (int i = lane; i < kTableSize / 2; i += 64) {
-      const uint32_t v = t32[i];
-      const uint32_t d0 = (R + 1u - v) & 0xffffu, d1 = (R + 1u - (v >> 16)) & 0xffffu;
-      const uint32_t lo = (d0 == 0 || d0 > 32768u) ? marker : (v & 0xffffu);
-      const uint32_t hi = (d1 == 0 || d1 > 32768u) ? marker : (v >> 16);
-      t32[i] = lo | (hi << 16);
+    // (sixteen words per lane in flight: a guest's table is in memory, and one load at a time, each
+    // waited for before its store, was 128 round trips per sweep, eight sweeps per window)
+    static_assert(kTableSize / 2 % (64 * 16) == 0, "table = whole rounds of 16 dwords per lane");
+    for (int i0 = lane; i0 < kTableSize / 2; i0 += 64 * 16) {
+      uint32_t w[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) w[k] = t32[i0 + 64 * k];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const uint32_t v = w[k];
+        const uint32_t d0 = (R + 1u - v) & 0xffffu, d1 = (R + 1u - (v >> 16)) & 0xffffu;
+        const uint32_t lo = (d0 == 0 || d0 > 32768u) ? marker : (v & 0xffffu);
+        const uint32_t hi = (d1 == 0 || d1 > 32768u) ? marker : (v >> 16);
+        t32[i0 + 64 * k] = lo | (hi << 16);
+      }
     }
     __syncthreads();
     next_sweep = R + kSweepEvery;
