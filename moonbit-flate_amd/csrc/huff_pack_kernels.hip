@@ -39,7 +39,12 @@ constexpr int kHdrMax = 704;
 // codegen_order, huffman-bit-writer.mbt:83-85 (RFC 1951 3.2.7)
 __constant__ uint8_t kCodegenOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
-// LDS of huff_code_kernel
+// LDS of huff_code_kernel.  The kernel is latency-bound and this struct decides how many wavefronts
+// a CU holds (12 KiB: 13), so arrays whose lives do not overlap share their bytes: the codegen items
+// sit in the sort keys (dead once a code's leaves are sorted; the 19-symbol codegen code built while
+// the items are live touches the first 76 bytes only), the header entries in the second
+// package-merge list (idle once the last code is built).
+constexpr int kPmLevels = 14;  // package-merge levels 2 .. 15 keep a leaf bitmap
 struct Shared {
   uint32_t lit_freq[288];
   uint32_t off_freq[32];
@@ -48,24 +53,22 @@ struct Shared {
   uint32_t off_cl[32];
   uint32_t cg_cl[20];
   // code construction scratch
-  uint32_t key[288];    // sort keys, then sorted leaf frequencies
+  uint32_t key[288];    // sort keys (freq << 9 | symbol) of the symbols in use
   uint32_t sfreq[288];  // leaves ascending by (freq, symbol)
-  uint16_t ssym[288];
-  uint32_t lv[2][576];  // package-merge level lists (ping-pong)
+  alignas(8) uint32_t lv[2][576];  // package-merge level lists (ping-pong)
   uint32_t pairs[288];
-  uint32_t leaf_bits[16][18];  // per level: bit r set <=> item r of the merged list is a leaf
+  uint32_t leaf_bits[kPmLevels][18];  // per level: bit r set <=> item r of the merged list is a leaf
   uint8_t slen[288];
-  uint32_t counts[17];
-  uint32_t first_code[17];
-  uint32_t len_base[17];
-  // header
-  uint8_t codegen[320];    // the codegen symbols (0..18), one per item
-  uint8_t cg_extra[320];   // the repeat count carried by a 16 / 17 / 18 item
-  uint32_t cg_n;           // number of items
-  uint16_t hdr_val[kHdrMax];
-  uint8_t hdr_nb[kHdrMax];
+  uint32_t cg_n;           // number of codegen items
   uint32_t hdr_n;
+  // header
+  FLATE_D uint8_t *codegen() { return reinterpret_cast<uint8_t *>(key) + 128; }   // [320] the codegen symbols (0..18), one per item
+  FLATE_D uint8_t *cg_extra() { return reinterpret_cast<uint8_t *>(key) + 448; }  // [320] the repeat count carried by a 16 / 17 / 18 item
+  FLATE_D uint16_t *hdr_val() { return reinterpret_cast<uint16_t *>(&lv[1][0]); }            // [kHdrMax]
+  FLATE_D uint8_t *hdr_nb() { return reinterpret_cast<uint8_t *>(&lv[1][0]) + 2 * kHdrMax; }  // [kHdrMax]
 };
+static_assert(448 + 320 <= sizeof(uint32_t) * 288, "codegen items fit the sort keys");
+static_assert(3 * kHdrMax <= (int)sizeof(uint32_t) * 576, "header entries fit a level list");
 
 // LDS of huff_hist_kernel
 struct SharedHist {
@@ -220,6 +223,175 @@ FLATE_D void sink_finish(BitSink &S, int lane) {
 
 // ---- canonical length-limited Huffman code (huffman-code.mbt:295-343) ----------------
 // freq[0..nsym) -> cl[i] = (len << 16) | reversed code; len = 0 for absent symbols.
+//
+// The kernel is bound by the length of one block's dependent chain of LDS round trips (15 KiB of
+// scratch allow few wavefronts per CU), so everything that is a chain of dependent LDS reads in
+// the textbook form is kept short here: the binary searches of a level are branch-free with a
+// wave-uniform trip count, all of a lane's searches (its <= NT leaves and <= NT pairs) advance
+// together -- one round trip per halving, not one per search and halving -- and the per-level
+// counts, the canonical first codes and the length classes live in registers (one level per lane)
+// instead of LDS arrays walked by lane 0.
+//
+// build_code_sorted<NT>: the n > 2 symbols in use are in sh.key[0..n) as (freq << 9 | symbol);
+// a lane owns items lane, lane + 64, ... (NT >= ceil(n / 64) of them).
+template <int NT>
+FLATE_D void build_code_sorted(Shared &sh, int n, int nsym, int max_bits, uint32_t *cl, int lane) {
+  // rank sort (keys are distinct): item j of the unsorted list is leaf rank[j] of the sorted one
+  uint32_t mine[NT];
+  int rank[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int j = lane + 64 * t;
+    mine[t] = j < n ? sh.key[j] : 0xffffffffu;
+    rank[t] = 0;
+  }
+  for (int k = 0; k < n; ++k) {
+    const uint32_t kk = sh.key[k];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) rank[t] += kk < mine[t];
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+    if (lane + 64 * t < n) {
+      sh.sfreq[rank[t]] = mine[t] >> 9;   // leaves ascending by (freq, symbol), by_frequency :346
+      sh.lv[0][rank[t]] = mine[t] >> 9;   // level 1: the leaves themselves
+    }
+  for (int i = lane; i < kPmLevels * 18; i += 64) (&sh.leaf_bits[0][0])[i] = 0;
+  __syncthreads();
+
+  const int mb = max_bits < n - 1 ? max_bits : n - 1;  // :126-129
+  uint32_t lf[NT];  // my leaves of the SORTED list: i = lane + 64 t
+#pragma unroll
+  for (int t = 0; t < NT; ++t) lf[t] = lane + 64 * t < n ? sh.sfreq[lane + 64 * t] : 0u;
+  const int s0 = 1 << (31 - __builtin_clz(n));  // first step of a search over <= n elements
+
+  int lp = n;  // length of the previous level's list
+  int cur = 0;
+  for (int lvl = 2; lvl <= mb; ++lvl) {
+    const uint32_t *prev = sh.lv[cur];
+    uint32_t *next = sh.lv[cur ^ 1];
+    const int np = lp >> 1;  // >= 1, < n
+    uint32_t ps[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int j = lane + 64 * t;
+      const uint2 two = j < np ? *reinterpret_cast<const uint2 *>(prev + 2 * j) : make_uint2(0u, 0u);
+      ps[t] = two.x + two.y;
+      if (j < np) sh.pairs[j] = ps[t];
+    }
+    __syncthreads();
+    // leaf i goes to i + #pairs with sum <= leaf (a pair wins a tie, :187);
+    // pair j goes to j + #leaves with freq < sum.  Both lists are ascending: the count is built
+    // bit by bit from the top (element c + s - 1 satisfies the test <=> the count is >= c + s).
+    int cl_[NT], cp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) cl_[t] = cp[t] = 0;
+    for (int s = s0; s >= 1; s >>= 1) {
+      uint32_t pv[NT], lv_[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int a = cl_[t] + s, c = cp[t] + s;
+        pv[t] = sh.pairs[(a <= np ? a : np) - 1];
+        lv_[t] = sh.sfreq[(c <= n ? c : n) - 1];
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int a = cl_[t] + s, c = cp[t] + s;
+        cl_[t] = (a <= np && pv[t] <= lf[t]) ? a : cl_[t];
+        cp[t] = (c <= n && lv_[t] < ps[t]) ? c : cp[t];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int i = lane + 64 * t;
+      if (i < n) {
+        const int r = i + cl_[t];
+        next[r] = lf[t];
+        atomicOr(&sh.leaf_bits[lvl - 2][r >> 5], 1u << (r & 31));
+      }
+      if (i < np) next[i + cp[t]] = ps[t];
+    }
+    __syncthreads();
+    lp = n + np;
+    cur ^= 1;
+  }
+
+  // top-down: how many leaves sit in the needed prefix of each level (:168, :234-243).
+  // Lane w < 18 holds word w of every level's leaf bitmap; lane L collects counts[L].
+  uint32_t lb[kPmLevels];
+#pragma unroll
+  for (int k = 0; k < kPmLevels; ++k) lb[k] = (k + 2 <= mb && lane < 18) ? sh.leaf_bits[k][lane] : 0u;
+  uint32_t cnt_v = 0;  // lane L: counts[L] (counts[0] = 0)
+  {
+    uint32_t m = 2u * (uint32_t)n - 2u;
+#pragma unroll
+    for (int lvl = kPmLevels + 1; lvl >= 2; --lvl)
+      if (lvl <= mb) {
+        const int lo = lane * 32;
+        const uint32_t keep = (int)m >= lo + 32 ? 0xffffffffu : ((int)m <= lo ? 0u : ((1u << (m - lo)) - 1u));
+        const uint32_t a = wave_sum((uint32_t)__popc(lb[lvl - 2] & keep));
+        if (lane == lvl) cnt_v = a;
+        m = 2u * (m - a);
+      }
+    const uint32_t a1 = m < (uint32_t)n ? m : (uint32_t)n;  // level 1 holds only leaves
+    if (lane == 1) cnt_v = a1;
+  }
+  // bit_count[b] = counts[mb-b+1] - counts[mb-b] in lane b; len_base[b] = symbols with length <= b,
+  // counted from the most frequent; canonical first codes (:250-280)
+  const bool is_len = lane >= 1 && lane <= mb;
+  const uint32_t c_hi = __shfl(cnt_v, is_len ? mb - lane + 1 : 0);
+  const uint32_t c_lo = __shfl(cnt_v, is_len ? mb - lane : 0);
+  const uint32_t bc_v = is_len ? c_hi - c_lo : 0u;
+  const uint32_t len_base_v = wave_incl_scan(bc_v);
+  uint32_t first_code[16];  // (wave-uniform)
+  {
+    uint32_t code = 0;
+    first_code[0] = 0;
+#pragma unroll
+    for (int b = 1; b < 16; ++b) {
+      code <<= 1;
+      first_code[b] = code;
+      code += rdlane(bc_v, b);  // 0 beyond mb
+    }
+  }
+  // the len_base[b] - len_base[b-1] most frequent leaves not yet served get length b
+  {
+    int bl[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bl[t] = 1;
+#pragma unroll
+    for (int k = 1; k < 15; ++k)
+      if (k < mb) {
+        const uint32_t lbk = rdlane(len_base_v, k);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bl[t] += (uint32_t)(n - 1 - rank[t]) >= lbk;  // 0 = most frequent
+      }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      if (lane + 64 * t < n) sh.slen[mine[t] & 511u] = (uint8_t)bl[t];
+  }
+  __syncthreads();
+  // codes in symbol order within each length
+  uint32_t running[16];
+#pragma unroll
+  for (int b = 0; b < 16; ++b) running[b] = 0;
+  for (int base = 0; base < nsym; base += 64) {
+    const int i = base + lane;
+    const uint32_t L = i < nsym ? sh.slen[i] : 0u;
+    uint32_t code = 0;
+#pragma unroll
+    for (int b = 1; b < 16; ++b) {
+      const uint64_t m = __ballot(L == (uint32_t)b);
+      if (L == (uint32_t)b) code = first_code[b] + running[b] + __popcll(m & ((1ull << lane) - 1));
+      running[b] += __popcll(m);
+    }
+    if (L) cl[i] = (L << 16) | (__brev(code) >> (32 - L));
+  }
+  __syncthreads();
+}
+
+// MAXT = ceil(nsym / 64)
+template <int MAXT>
 FLATE_D void build_code(Shared &sh, const uint32_t *freq, int nsym, int max_bits, uint32_t *cl,
                         int lane) {
   // compact the symbols with non-zero frequency, in symbol order
@@ -244,142 +416,16 @@ FLATE_D void build_code(Shared &sh, const uint32_t *freq, int nsym, int max_bits
     __syncthreads();
     return;
   }
-
-  // rank sort (keys are distinct)
-  {
-    uint32_t mine[5];
-    int rank[5];
-#pragma unroll
-    for (int t = 0; t < 5; ++t) {
-      const int j = lane + 64 * t;
-      mine[t] = j < n ? sh.key[j] : 0xffffffffu;
-      rank[t] = 0;
-    }
-    for (int k = 0; k < n; ++k) {
-      const uint32_t kk = sh.key[k];
-#pragma unroll
-      for (int t = 0; t < 5; ++t) rank[t] += kk < mine[t];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < 5; ++t) {
-      const int j = lane + 64 * t;
-      if (j < n) {
-        sh.sfreq[rank[t]] = mine[t] >> 9;
-        sh.ssym[rank[t]] = (uint16_t)(mine[t] & 511u);
-      }
-    }
-    __syncthreads();
+  if constexpr (MAXT == 1) {
+    build_code_sorted<1>(sh, n, nsym, max_bits, cl, lane);
+  } else {
+    if (n <= 128)
+      build_code_sorted<2>(sh, n, nsym, max_bits, cl, lane);
+    else if (n <= 192)
+      build_code_sorted<3>(sh, n, nsym, max_bits, cl, lane);
+    else
+      build_code_sorted<MAXT>(sh, n, nsym, max_bits, cl, lane);
   }
-
-  const int mb = max_bits < n - 1 ? max_bits : n - 1;  // :126-129
-
-  // level 1: the leaves themselves
-  for (int i = lane; i < n; i += 64) sh.lv[0][i] = sh.sfreq[i];
-  for (int i = lane; i < 16 * 18; i += 64) (&sh.leaf_bits[0][0])[i] = 0;
-  __syncthreads();
-  int lp = n;  // length of the previous level's list
-  int cur = 0;
-  for (int lvl = 2; lvl <= mb; ++lvl) {
-    const uint32_t *prev = sh.lv[cur];
-    uint32_t *next = sh.lv[cur ^ 1];
-    const int np = lp >> 1;
-    for (int j = lane; j < np; j += 64) sh.pairs[j] = prev[2 * j] + prev[2 * j + 1];
-    __syncthreads();
-    // leaves: rank = i + #pairs with sum <= leaf (a pair wins a tie, :187)
-    for (int i = lane; i < n; i += 64) {
-      const uint32_t f = sh.sfreq[i];
-      int lo = 0, hi = np;
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (sh.pairs[mid] <= f)
-          lo = mid + 1;
-        else
-          hi = mid;
-      }
-      const int r = i + lo;
-      next[r] = f;
-      atomicOr(&sh.leaf_bits[lvl][r >> 5], 1u << (r & 31));
-    }
-    // pairs: rank = j + #leaves with freq < sum
-    for (int j = lane; j < np; j += 64) {
-      const uint32_t ps = sh.pairs[j];
-      int lo = 0, hi = n;
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (sh.sfreq[mid] < ps)
-          lo = mid + 1;
-        else
-          hi = mid;
-      }
-      next[j + lo] = ps;
-    }
-    __syncthreads();
-    lp = n + np;
-    cur ^= 1;
-  }
-
-  // top-down: how many leaves sit in the needed prefix of each level (:168, :234-243)
-  {
-    uint32_t m = 2u * (uint32_t)n - 2u;
-    for (int lvl = mb; lvl >= 1; --lvl) {
-      uint32_t a;
-      if (lvl == 1) {
-        a = m < (uint32_t)n ? m : (uint32_t)n;  // level 1 holds only leaves
-      } else {
-        uint32_t part = 0;
-        if (lane < 18) {
-          const uint32_t wbits = sh.leaf_bits[lvl][lane];
-          const int lo = lane * 32;
-          const uint32_t keep = (int)m >= lo + 32 ? 0xffffffffu : ((int)m <= lo ? 0u : ((1u << (m - lo)) - 1u));
-          part = __popc(wbits & keep);
-        }
-        a = wave_sum(part);
-      }
-      if (lane == 0) sh.counts[lvl] = a;
-      m = 2u * (m - a);
-    }
-    if (lane == 0) sh.counts[0] = 0;
-  }
-  __syncthreads();
-  // bit_count[b] = counts[mb-b+1] - counts[mb-b]; canonical first codes (:250-280)
-  if (lane == 0) {
-    uint32_t code = 0, cum = 0;
-    for (int b = 1; b <= mb; ++b) {
-      const uint32_t bc = sh.counts[mb - b + 1] - sh.counts[mb - b];
-      code <<= 1;
-      sh.first_code[b] = code;
-      code += bc;
-      cum += bc;
-      sh.len_base[b] = cum;  // symbols with length <= b, counted from the most frequent
-    }
-  }
-  __syncthreads();
-  // the n - len_base[b-1] .. most frequent leaves get the shortest codes
-  for (int j = lane; j < n; j += 64) {
-    const uint32_t from_top = (uint32_t)(n - 1 - j);  // 0 = most frequent
-    int b = 1;
-    while (b < mb && from_top >= sh.len_base[b]) ++b;
-    sh.slen[sh.ssym[j]] = (uint8_t)b;
-  }
-  __syncthreads();
-  // codes in symbol order within each length
-  uint32_t running[16];
-#pragma unroll
-  for (int b = 0; b < 16; ++b) running[b] = 0;
-  for (int base = 0; base < nsym; base += 64) {
-    const int i = base + lane;
-    const uint32_t L = i < nsym ? sh.slen[i] : 0u;
-    uint32_t code = 0;
-#pragma unroll
-    for (int b = 1; b < 16; ++b) {
-      const uint64_t m = __ballot(L == (uint32_t)b);
-      if (L == (uint32_t)b) code = sh.first_code[b] + running[b] + __popcll(m & ((1ull << lane) - 1));
-      running[b] += __popcll(m);
-    }
-    if (L) cl[i] = (L << 16) | (__brev(code) >> (32 - L));
-  }
-  __syncthreads();
 }
 
 // ---- tile walk over the implied token sequence ----------------------------------------
@@ -577,20 +623,20 @@ FLATE_D uint32_t make_header(Shared &sh, int num_literals, int num_offsets, int 
     if (r < nruns) {
       const uint32_t big_sym = v != 0 ? 16u : 18u, big_extra = v != 0 ? 3u : 127u;
       if (v != 0) {  // the first occurrence is always written plainly (:276-279)
-        sh.codegen[at] = (uint8_t)v;
-        sh.cg_extra[at++] = 0;
+        sh.codegen()[at] = (uint8_t)v;
+        sh.cg_extra()[at++] = 0;
       }
       for (uint32_t k = 0; k < k_big; ++k) {
-        sh.codegen[at] = (uint8_t)big_sym;
-        sh.cg_extra[at++] = (uint8_t)big_extra;
+        sh.codegen()[at] = (uint8_t)big_sym;
+        sh.cg_extra()[at++] = (uint8_t)big_extra;
       }
       if (has_tail) {
-        sh.codegen[at] = (uint8_t)tail_sym;
-        sh.cg_extra[at++] = (uint8_t)tail_extra;
+        sh.codegen()[at] = (uint8_t)tail_sym;
+        sh.cg_extra()[at++] = (uint8_t)tail_extra;
       }
       for (uint32_t k = v != 0 ? 1u : 0u; k < plain; ++k) {
-        sh.codegen[at] = (uint8_t)v;
-        sh.cg_extra[at++] = 0;
+        sh.codegen()[at] = (uint8_t)v;
+        sh.cg_extra()[at++] = 0;
       }
       if (plain) atomicAdd(&sh.cg_freq[v], plain);
       const uint32_t n_big = k_big + ((has_tail && tail_sym == big_sym) ? 1u : 0u);
@@ -600,7 +646,7 @@ FLATE_D uint32_t make_header(Shared &sh, int num_literals, int num_offsets, int 
   }
   if (lane == 0) sh.cg_n = nitems;
   __syncthreads();
-  build_code(sh, sh.cg_freq, kCodegenCodeCount, 7, sh.cg_cl, lane);
+  build_code<1>(sh, sh.cg_freq, kCodegenCodeCount, 7, sh.cg_cl, lane);
 
   // (3) header entries: HLIT, HDIST, HCLEN, the code lengths of the codegen code in codegen_order
   // (trailing zeros dropped, at least four), then the items (:421-471)
@@ -616,35 +662,35 @@ FLATE_D uint32_t make_header(Shared &sh, int num_literals, int num_offsets, int 
   }
   const uint32_t size = 3u + 5u + 5u + 4u + 3u * (uint32_t)ncg + wave_sum(term);
   if (lane == 0) {
-    sh.hdr_val[0] = 4;  // BFINAL=0, BTYPE=10 (callers never pass eof, deflate.mbt:251,267,269)
-    sh.hdr_nb[0] = 3;
-    sh.hdr_val[1] = (uint16_t)(num_literals - 257);
-    sh.hdr_nb[1] = 5;
-    sh.hdr_val[2] = (uint16_t)(num_offsets - 1);
-    sh.hdr_nb[2] = 5;
-    sh.hdr_val[3] = (uint16_t)(ncg - 4);
-    sh.hdr_nb[3] = 4;
+    sh.hdr_val()[0] = 4;  // BFINAL=0, BTYPE=10 (callers never pass eof, deflate.mbt:251,267,269)
+    sh.hdr_nb()[0] = 3;
+    sh.hdr_val()[1] = (uint16_t)(num_literals - 257);
+    sh.hdr_nb()[1] = 5;
+    sh.hdr_val()[2] = (uint16_t)(num_offsets - 1);
+    sh.hdr_nb()[2] = 5;
+    sh.hdr_val()[3] = (uint16_t)(ncg - 4);
+    sh.hdr_nb()[3] = 4;
   }
   if (lane < ncg) {
-    sh.hdr_val[4 + lane] = (uint16_t)(sh.cg_cl[kCodegenOrder[lane]] >> 16);
-    sh.hdr_nb[4 + lane] = 3;
+    sh.hdr_val()[4 + lane] = (uint16_t)(sh.cg_cl[kCodegenOrder[lane]] >> 16);
+    sh.hdr_nb()[4 + lane] = 3;
   }
   uint32_t h = 4u + (uint32_t)ncg;
   for (uint32_t k0 = 0; k0 < nitems; k0 += 64) {
     const uint32_t k = k0 + (uint32_t)lane;
     const bool live = k < nitems;
-    const uint32_t cw = live ? sh.codegen[k] : 0u;
+    const uint32_t cw = live ? sh.codegen()[k] : 0u;
     const uint32_t ents = live ? (cw >= 16u ? 2u : 1u) : 0u;
     const uint32_t incl = wave_incl_scan(ents);
     const uint32_t at = h + incl - ents;
     h += rdlane(incl, 63);
     if (live) {
       const uint32_t c = sh.cg_cl[cw];
-      sh.hdr_val[at] = (uint16_t)(c & 0xffffu);
-      sh.hdr_nb[at] = (uint8_t)(c >> 16);
+      sh.hdr_val()[at] = (uint16_t)(c & 0xffffu);
+      sh.hdr_nb()[at] = (uint8_t)(c >> 16);
       if (cw >= 16u) {
-        sh.hdr_val[at + 1] = sh.cg_extra[k];
-        sh.hdr_nb[at + 1] = cw == 16u ? 2 : (cw == 17u ? 3 : 7);
+        sh.hdr_val()[at + 1] = sh.cg_extra()[k];
+        sh.hdr_nb()[at + 1] = cw == 16u ? 2 : (cw == 17u ? 3 : 7);
       }
     }
   }
@@ -798,7 +844,7 @@ __global__ __launch_bounds__(64) void huff_code_kernel(HuffParams P) {
       if (lane < 32) sh.off_freq[lane] = h[288 + lane];
       __syncthreads();
       int num_literals, num_offsets;
-      build_code(sh, sh.lit_freq, kMaxNumLit, 15, sh.lit_cl, lane);
+      build_code<5>(sh, sh.lit_freq, kMaxNumLit, 15, sh.lit_cl, lane);
       if (kind == 1) {  // write_block_huff (:738-776): huff_offset = code 0 of length 1
         num_literals = kEndBlockMarker + 1;
         num_offsets = 1;
@@ -816,7 +862,7 @@ __global__ __launch_bounds__(64) void huff_code_kernel(HuffParams P) {
           num_offsets = 1;
         }
         __syncthreads();
-        build_code(sh, sh.off_freq, kOffsetCodeCount, 15, sh.off_cl, lane);
+        build_code<1>(sh, sh.off_freq, kOffsetCodeCount, 15, sh.off_cl, lane);
       }
       hdr_bits = make_header(sh, num_literals, num_offsets, lane);
       uint32_t part = 0, extra = 0;
@@ -844,7 +890,7 @@ __global__ __launch_bounds__(64) void huff_code_kernel(HuffParams P) {
         if (lane < 32) cl[288 + lane] = sh.off_cl[lane];
         uint32_t *hd = P.blk_hdr + (uint64_t)gb * kHdrMax;
         const int hn = (int)sh.hdr_n;
-        for (int i = lane; i < hn; i += 64) hd[i] = ((uint32_t)sh.hdr_nb[i] << 16) | sh.hdr_val[i];
+        for (int i = lane; i < hn; i += 64) hd[i] = ((uint32_t)sh.hdr_nb()[i] << 16) | sh.hdr_val()[i];
       }
     }
     const uint64_t start = bitpos;
@@ -944,15 +990,23 @@ FLATE_D void pack_block(const HuffParams &P, SharedPack &sh, BitSink &S, const B
         w.bytes = load_bytes4(w, (t + 1) * kTile + 4 * lane);
         const uint32_t tok_next = tok_of(m_next);
         const uint32_t m_next2 = t + 2 < ntiles ? tmeta[(t + 2) * 64 + lane] : 0u;
-        uint64_t lo = 0;
-        uint32_t hi = 0, nb = 0;
+        uint64_t lo;
+        uint32_t hi = 0, nb;
+        {
+          // The codes of all four bytes are looked up at once (one LDS round trip, no branches) and
+          // those of covered positions masked off; pairs are joined in 32 bits (<= 30 each), the two
+          // pairs by one 64-bit shift.  At most three literals when a match follows: <= 45 bits.
+          uint32_t c[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if ((m_cur >> k) & 1u) {  // at most three when a match follows: <= 45 bits
-            const uint32_t c = sh.lit_cl[(bt >> (8 * k)) & 0xffu];
-            lo |= (uint64_t)(c & 0xffffu) << nb;
-            nb += c >> 16;
-          }
+          for (int k = 0; k < 4; ++k) c[k] = sh.lit_cl[(bt >> (8 * k)) & 0xffu];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) c[k] = ((m_cur >> k) & 1u) ? c[k] : 0u;
+          const uint32_t n0 = c[0] >> 16, n1 = c[1] >> 16, n2 = c[2] >> 16, n3 = c[3] >> 16;
+          const uint32_t p01 = (c[0] & 0xffffu) | ((c[1] & 0xffffu) << n0);
+          const uint32_t p23 = (c[2] & 0xffffu) | ((c[3] & 0xffffu) << n2);
+          lo = (uint64_t)p01 | ((uint64_t)p23 << (n0 + n1));
+          nb = n0 + n1 + n2 + n3;
+        }
         if (m_cur & 0x10u) {
           const CodeBits lc = length_code_of((tok_cur >> kLengthShift) & 0xffu);
           const CodeBits oc = offset_code_of(tok_cur & ((1u << kLengthShift) - 1u));
