@@ -74,15 +74,22 @@ static_assert(3 * kHdrMax <= (int)sizeof(uint32_t) * 576, "header entries fit a 
 struct SharedHist {
   uint32_t lit_freq[288];
   uint32_t off_freq[32];
-  // per-tile scatter target, one byte per position (lane L reads its four as one dword):
-  uint4 marks[kTile / 4];  // .x: 1 at the first position a match covers (start + 1), .y: 1 just past
-                           // a match, .z: 1 at a match start
-  uint32_t tok[kTile];     // the token of the match that starts at a position
+  // per-tile scatter target, one byte per position (lane L reads its four as one dword): 1 = the
+  // first position a match covers (start + 1), 2 = the last one, 4 = a match starts here.  Matches
+  // are >= 4 long and do not overlap, so no position ever gets two marks: plain byte stores.
+  uint32_t marks[kTile / 4];
+  uint8_t len_code[256];   // length - 3 -> length code (token.mbt:30-44), filled once per wavefront
 };
+FLATE_D void fill_len_code(SharedHist &sh, int lane) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) sh.len_code[4 * lane + k] = (uint8_t)length_code_of((uint32_t)(4 * lane + k)).code;
+  __syncthreads();
+}
 
 struct SharedPack {
   uint32_t lit_cl[288];
   uint32_t off_cl[32];
+  uint32_t len_bits[256];  // per block, by length - 3: (bits << 24) | length code + extra bits (<= 15 + 5)
   uint32_t ring[kRing];
 };
 
@@ -432,16 +439,19 @@ FLATE_D void build_code(Shared &sh, const uint32_t *freq, int nsym, int max_bits
 // A tile is 256 consecutive input positions; lane L owns positions P0 + 4L .. P0 + 4L + 3.
 // At most one match can start inside a lane's four positions (matches are >= 4 long).
 struct TileTok {
-  uint32_t bytes;     // the lane's four input bytes (little endian)
-  uint32_t lit_mask;  // bit k: position k is a literal
-  int match_k;        // 0..3: a match starts at position k; -1: none
-  uint32_t tok;       // its token
+  uint32_t bytes;  // the lane's four input bytes (little endian)
+  uint32_t lit;    // byte k = 1: position k is a literal
+  uint32_t start;  // byte k = 1: a match starts at position k (at most one byte set)
+  uint32_t tok;    // its token
   // What huff_pack_kernel needs to know about a lane's four positions, in one byte: the walk is
   // done once, by huff_hist_kernel, and handed over through HuffParams::tile_meta (64 bytes per
-  // tile).  The j-th lane of a tile with bit 4 set starts the j-th match record of that tile.
-  // Positions after a match start are covered (matches are >= 4 long), so the literals of a lane
-  // all precede its match.
-  FLATE_D uint32_t pack() const { return lit_mask | (match_k >= 0 ? 0x10u | ((uint32_t)match_k << 5) : 0u); }
+  // tile): bits 0..3 = literal at position k, bit 4 = a match starts in the lane, bits 5..6 = at
+  // which position.  The j-th lane of a tile with bit 4 set starts the j-th match record of that
+  // tile.  Positions after a match start are covered (matches are >= 4 long), so the literals of a
+  // lane all precede its match.  Two byte dot products (v_dot4_u32_u8) build it from the flags.
+  FLATE_D uint32_t pack() const {
+    return __builtin_amdgcn_udot4(lit, 0x08040201u, __builtin_amdgcn_udot4(start, 0x70503010u, 0u, false), false);
+  }
 };
 // Where a block's tile rows (64 bytes per 256-position tile) start in HuffParams::tile_meta: by
 // the block's position in the input plus its index, so that the whole array is input / 4 bytes
@@ -495,8 +505,9 @@ FLATE_D Walker walker_init(const uint8_t *src, const uint2 *recs, uint32_t nm, i
 FLATE_D int clamp04(int v) { return v < 0 ? 0 : (v > 4 ? 4 : v); }  // (v_med3_i32)
 // Byte-parallel form: the marks of a lane's four positions are the four bytes of a dword, so a
 // multiply by 0x01010101 is their inclusive prefix sum (sums <= 4: no carry between bytes) and the
-// classification of the four positions is straight-line dword arithmetic.  lit_mask comes out with
-// one more multiply (bytes 0/1 at bits 0, 8, 16, 24 -> bits 24..27).
+// classification of the four positions is straight-line dword arithmetic.  (v_mul_lo_u32 is a
+// quarter-rate instruction: the sums the walk needs come from v_sad_u8, the prefix sums from two
+// shift-adds, the packed result from v_dot4_u32_u8.)
 FLATE_D TileTok walk_tile(SharedHist &sh, Walker &w, int P0, int lane) {
   TileTok t;
   const int pos = P0 + 4 * lane;
@@ -508,35 +519,45 @@ FLATE_D TileTok walk_tile(SharedHist &sh, Walker &w, int P0, int lane) {
   w.mp += (uint32_t)cnt;
   w.rec = load_rec(w, w.mp, lane);
   w.bytes = load_bytes4(w, pos + kTile);
-  sh.marks[lane] = make_uint4(0, 0, 0, 0);
+  sh.marks[lane] = 0;
   __syncthreads();
   const uint32_t mlen = ((rec.y >> kLengthShift) & 0xffu) + 3u;
   if (mine) {
-    uint8_t *mb = reinterpret_cast<uint8_t *>(sh.marks);  // position o: byte (o >> 2) * 16 + field * 4 + (o & 3)
+    uint8_t *mb = reinterpret_cast<uint8_t *>(sh.marks);
     const uint32_t o = rec.x - (uint32_t)P0;
-    mb[(o >> 2) * 16u + 8u + (o & 3u)] = 1;
-    sh.tok[o] = rec.y;
-    const uint32_t o1 = o + 1u, o2 = o + mlen;
-    if (o1 < (uint32_t)kTile) mb[(o1 >> 2) * 16u + (o1 & 3u)] = 1;
-    if (o2 < (uint32_t)kTile) mb[(o2 >> 2) * 16u + 4u + (o2 & 3u)] = 1;
+    mb[o] = 4;
+    const uint32_t o1 = o + 1u, o2 = o + mlen - 1u;
+    if (o1 < (uint32_t)kTile) mb[o1] = 1;
+    if (o2 < (uint32_t)kTile) mb[o2] = 2;
   }
   __syncthreads();
-  const uint4 m = sh.marks[lane];
-  const uint32_t pc = m.x * 0x01010101u, nc = m.y * 0x01010101u;  // inclusive prefix sums per byte
-  const uint32_t tot = (pc >> 24) - (nc >> 24);                   // net coverage change of this lane
-  const uint32_t base = wave_incl_scan(tot) - tot;                // coverage entering this lane: 0 or 1
+  const uint32_t m = sh.marks[lane];
+  const uint32_t first = m & 0x01010101u, last = (m >> 1) & 0x01010101u;
+  // net coverage change of this lane: marks are bytes 0 / 1, v_sad_u8 against 0 sums four of them
+  const uint32_t tot = __builtin_amdgcn_sad_u8(first, 0u, 0u) - __builtin_amdgcn_sad_u8(last, 0u, 0u);
+  const uint32_t base = wave_incl_scan(tot) - tot;  // coverage entering this lane: 0 or 1
   // positions below cov_until are covered by a match of an earlier tile: the t lowest bytes
   const int t_lo = clamp04((int)w.cov_until - pos);
   const uint32_t low = (uint32_t)((0x01010101ull << (8 * t_lo)) >> 32);
   if (cnt) w.cov_until = rdlane(rec.x, cnt - 1) + rdlane(mlen, cnt - 1);
-  const uint32_t cov = (pc + base * 0x01010101u - nc) | low;  // bytes 0 / 1 (coverage never negative)
+  // coverage of position k = coverage entering the lane + firsts up to k - lasts before k: per-byte
+  // inclusive prefix sums of first - (last << 8), x * 0x01010101 as two shift-adds (the borrows
+  // between the bytes cancel in the sums; the coverage itself is 0 or 1 in every byte).
+  // (inline asm: written in C the compiler folds the two steps back into a quarter-rate multiply)
+  const uint32_t e = first - (last << 8) + base;
+  uint32_t e2, e4;
+  asm("v_lshl_add_u32 %0, %1, 8, %1" : "=v"(e2) : "v"(e));
+  asm("v_lshl_add_u32 %0, %1, 16, %1" : "=v"(e4) : "v"(e2));
+  const uint32_t cov = e4 | low;
   const int t_act = clamp04(w.n - pos);  // my positions inside the chunk
   const uint32_t act = (uint32_t)((0x01010101ull << (8 * t_act)) >> 32);
-  const uint32_t start = m.z & act;
-  const uint32_t lit = act & ~(cov | start);
-  t.lit_mask = (lit * 0x01020408u) >> 24;
-  t.match_k = start ? (int)(__builtin_ctz(start) >> 3) : -1;
-  t.tok = start ? sh.tok[4 * lane + t.match_k] : 0u;
+  t.start = (m >> 2) & act;
+  t.lit = act & ~(cov | t.start);
+  // token of the match that starts here: the j-th lane with a start owns the j-th record of the tile
+  // (records are sorted, a lane holds at most one start), fetched from the lane that loaded it
+  const uint64_t sb = __ballot(t.start != 0);
+  const uint32_t tk = (uint32_t)__shfl((int)rec.y, (int)__popcll(sb & ((1ull << lane) - 1ull)));
+  t.tok = t.start ? tk : 0u;
   return t;
 }
 
@@ -779,15 +800,15 @@ FLATE_D void hist_block(const HuffParams &P, SharedHist &sh, const BlockGeom &g,
       for (int P0 = 0; P0 < n; P0 += kTile) {
         const TileTok t = walk_tile(sh, w, P0, lane);
         tmeta[(P0 >> 2) + lane] = (uint8_t)t.pack();
-        if (t.match_k >= 0) {
-          const CodeBits lc = length_code_of((t.tok >> kLengthShift) & 0xffu);
+        if (t.start) {
+          const uint32_t lcode = sh.len_code[(t.tok >> kLengthShift) & 0xffu];
           const CodeBits oc = offset_code_of(t.tok & ((1u << kLengthShift) - 1u));
-          atomicAdd(&lit_freq[kLengthCodesStart + lc.code], 1u);
+          atomicAdd(&lit_freq[kLengthCodesStart + lcode], 1u);
           atomicAdd(&off_freq[oc.code], 1u);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-          if ((t.lit_mask >> k) & 1u) atomicAdd(&lit_freq[(t.bytes >> (8 * k)) & 0xffu], 1u);
+          if ((t.lit >> (8 * k)) & 1u) atomicAdd(&lit_freq[(t.bytes >> (8 * k)) & 0xffu], 1u);
       }
       if (lane == 0) atomicAdd(&lit_freq[kEndBlockMarker], 1u);  // tokens.push(EOB), :507
     }
@@ -804,6 +825,7 @@ __global__ __launch_bounds__(64) void huff_hist_kernel(HuffParams P) {
   const uint32_t sid = blockIdx.x + P.sid0;
   if (sid >= P.n_streams) return;
   const BlockGeom g = block_geom(P, sid);
+  fill_len_code(sh, lane);
   for (uint32_t b = 0; b < g.nblocks; ++b) hist_block(P, sh, g, b, lane);
 }
 
@@ -815,6 +837,7 @@ __global__ __launch_bounds__(64) void huff_hist_block_kernel(HuffParams P) {
   const uint32_t gb = blockIdx.x;
   const uint32_t sid = P.blk_sid[gb];
   const BlockGeom g = block_geom(P, sid);
+  fill_len_code(sh, lane);
   hist_block(P, sh, g, gb - g.blk0, lane);
 }
 
@@ -937,6 +960,16 @@ FLATE_D void pack_block(const HuffParams &P, SharedPack &sh, BitSink &S, const B
     for (int i = lane; i < 288; i += 64) sh.lit_cl[i] = cl[i];
     if (lane < 32) sh.off_cl[lane] = cl[288 + lane];
     __syncthreads();
+    if (kind == 2) {  // everything a match length contributes, by length - 3
+#pragma unroll 1
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t x = 4u * (uint32_t)lane + (uint32_t)k;
+        const CodeBits lc = length_code_of(x);
+        const uint32_t c1 = sh.lit_cl[kLengthCodesStart + lc.code];
+        sh.len_bits[x] = (((c1 >> 16) + lc.nextra) << 24) | (c1 & 0xffffu) | (lc.extra << (c1 >> 16));
+      }
+      __syncthreads();
+    }
     {  // header items written by huff_code_kernel
       const uint32_t *hd = P.blk_hdr + (uint64_t)gb * kHdrMax;
       const int hn = (int)meta.y;
@@ -1008,14 +1041,13 @@ FLATE_D void pack_block(const HuffParams &P, SharedPack &sh, BitSink &S, const B
           nb = n0 + n1 + n2 + n3;
         }
         if (m_cur & 0x10u) {
-          const CodeBits lc = length_code_of((tok_cur >> kLengthShift) & 0xffu);
+          const uint32_t lb = sh.len_bits[(tok_cur >> kLengthShift) & 0xffu];
           const CodeBits oc = offset_code_of(tok_cur & ((1u << kLengthShift) - 1u));
-          const uint32_t c1 = sh.lit_cl[kLengthCodesStart + lc.code];
           const uint32_t c2 = sh.off_cl[oc.code];
-          // length code + extra (<= 15 + 5 bits) and offset code + extra (<= 15 + 13) each in one
-          // dword, joined by a single 64-bit shift
-          const uint32_t n1 = (c1 >> 16) + lc.nextra;
-          const uint32_t part1 = (c1 & 0xffffu) | (lc.extra << (c1 >> 16));
+          // length code + extra (<= 15 + 5 bits, from the block's table) and offset code + extra
+          // (<= 15 + 13) each in one dword, joined by a single 64-bit shift
+          const uint32_t n1 = lb >> 24;
+          const uint32_t part1 = lb & 0xffffffu;
           const uint32_t part2 = (c2 & 0xffffu) | (oc.extra << (c2 >> 16));
           const uint64_t bits = part1 | ((uint64_t)part2 << n1);
           const uint32_t mb = n1 + (c2 >> 16) + oc.nextra;  // <= 48

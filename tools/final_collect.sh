@@ -1,19 +1,22 @@
 #!/bin/bash
 # End-of-round evidence run (one gpurun call): gpu tests, soak, default bench, the same bench under
 # rocprofv3 --kernel-trace --stats, fabric traffic of the match finder (configs 2 and 3) and of the
-# config-5 inflate launch.   usage: FLATE_GIT_HEAD=<commit> tools/final_collect.sh <tag>
+# config-5 inflate launch.   usage: FLATE_GIT_HEAD=<commit> [FLATE_SOAK_S=300] [FLATE_COLLECT_LITE=1] tools/final_collect.sh <tag>
+# FLATE_COLLECT_LITE=1 stops after the bench under rocprofv3: for changes that leave the match finder and the
+# inflaters alone (their build ids, hence the committed traffic figures and inflate profiles, stay valid).
 set -e
 tag=$1
 mkdir -p gpurun_out/$tag
 timeout -k 10 600 python3 -m pytest tests -m gpu -x -q > gpurun_out/$tag/gpu_tests.txt 2>&1 || { tail -20 gpurun_out/$tag/gpu_tests.txt; exit 1; }
 tail -1 gpurun_out/$tag/gpu_tests.txt
-timeout -k 10 900 python3 tests/tools/soak.py 300 > gpurun_out/$tag/soak.txt 2>&1 || { tail -20 gpurun_out/$tag/soak.txt; exit 1; }
+timeout -k 10 900 python3 tests/tools/soak.py ${FLATE_SOAK_S:-300} > gpurun_out/$tag/soak.txt 2>&1 || { tail -20 gpurun_out/$tag/soak.txt; exit 1; }
 tail -2 gpurun_out/$tag/soak.txt
 python3 -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/$tag/smoke.txt 2>&1 || { tail -5 gpurun_out/$tag/smoke.txt; exit 1; }
 tail -1 gpurun_out/$tag/smoke.txt
 python3 bench.py --steps 20 --warmup 5 > gpurun_out/$tag/bench.json 2> gpurun_out/$tag/bench.err
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/$tag/stats -o p --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-extra > gpurun_out/$tag/bench_under_rocprof.json 2> gpurun_out/$tag/rocprof.err
+if [ -n "$FLATE_COLLECT_LITE" ]; then echo collected-lite; exit 0; fi
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/$tag/stats_inf16k -o p --output-format csv -- python3 bench.py --mode inflate --streams 16384 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/$tag/inflate16k_under_rocprof.json 2> gpurun_out/$tag/rocprof_inf16k.err
 tools/traffic_collect.sh ${tag}_c2 16384 65536 > gpurun_out/$tag/traffic_c2.json 2> gpurun_out/$tag/traffic_c2.err
 tools/traffic_collect.sh ${tag}_c3 4096 262144 "--option window_units=0" > gpurun_out/$tag/traffic_c3.json 2> gpurun_out/$tag/traffic_c3.err
