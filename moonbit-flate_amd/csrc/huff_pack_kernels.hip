@@ -10,14 +10,15 @@
 //
 // Three kernels, one wavefront per stream each, split so that every phase runs at the
 // occupancy its LDS footprint allows:
-//   huff_hist_kernel  index_tokens: per-block symbol histograms          (~2 KiB LDS)
-//   huff_code_kernel  code construction, header, exact block bit sizes   (~15 KiB LDS, short)
+//   huff_hist_kernel  index_tokens: per-block symbol histograms          (1.8 KiB LDS; bound by the LDS pipe)
+//   huff_code_kernel  code construction, header, exact block bit sizes   (11.8 KiB LDS: 13 wavefronts per CU;
+//                     bound by one block's chain of dependent LDS round trips)
 //   huff_pack_kernel  write_dynamic_header + write_tokens, straight into the final
-//                     output at the offsets given by a scan of the exact sizes (~1.5 KiB LDS);
+//                     output at the offsets given by a scan of the exact sizes (4.3 KiB LDS; VALU-bound);
 //                     the token walk itself is handed over by huff_hist_kernel (tile_meta)
 // Everything that is a loop over tokens or symbols in the reference is a wave-parallel pass:
-//  * the token sequence is never materialised: each lane owns one input position of a
-//    64-byte tile and decides from the (sorted) match records whether it is a literal,
+//  * the token sequence is never materialised: each lane owns four input positions of a
+//    256-byte tile and decides from the (sorted) match records which of them are literals,
 //    the start of a match, or covered by one;
 //  * code lengths come from a level-parallel package-merge that yields the same counts
 //    as the lazy boundary algorithm of huffman-code.mbt:112-244 (ties between a leaf
