@@ -34,8 +34,12 @@ typedef struct flate_hip_ctx flate_hip_ctx;
 #define FLATE_HIP_E_HIP (-3)            /* HIP runtime failure (see strerror)         */
 #define FLATE_HIP_E_CORRUPT (-4)        /* inflate: corrupt_input_error (inflate.mbt:38) */
 #define FLATE_HIP_E_NO_DEVICE (-5)      /* no usable GPU: the engine has no CPU path  */
-#define FLATE_HIP_E_TOO_LARGE (-6)      /* stream >= 2 GiB - 128 KiB (buffer_reset,
-                                           deflate-fast.mbt:55: shift_offsets not built) */
+#define FLATE_HIP_E_TOO_LARGE (-6)      /* batch calls: a stream with an LZ77 window at index 32 766
+                                           (> 2 147 319 937 bytes; where the reference's `cur` reaches
+                                           buffer_reset and shift_offsets runs, deflate-fast.mbt:55,
+                                           130-132) or >= 2 GiB - 128 KiB with FLATE_HIP_COMPAT_GO:
+                                           write such a stream with flate_hip_stream_write, which follows
+                                           the reference through shift_offsets                        */
 #define FLATE_HIP_E_UNEXPECTED_EOF (-7) /* inflate: err_unexpected_eof (inflate.mbt:781) */
 #define FLATE_HIP_E_AGAIN (-9)          /* flate_hip_gather_end: a shard outgrew the agreed pad; the
                                            plan has been raised on every rank: repeat this batch
@@ -107,9 +111,12 @@ int flate_hip_set_stream(flate_hip_ctx *ctx, void *hip_stream);
  *                        producing, the gate of an overlapped sub-batch) give up after this many
  *                        polls and the call returns FLATE_HIP_E_INTERNAL (default 8 Mi polls,
  *                        several seconds of a running wave; time spent preempted does not count)
- *   "stream_rebase_bytes"  flate_hip_stream_*: a stream longer than this moves its origin up
- *                        (what shift_offsets does in the reference, deflate-fast.mbt:366-389);
+ *   "stream_rebase_bytes"  flate_hip_stream_*: a stream longer than this moves the origin of the
+ *                        32-bit positions its kernels count in (all distances stay what they were);
  *                        default 1 GiB, read when the stream is opened; results never change
+ *   "debug_buffer_reset"  test hook: buffer_reset (deflate-fast.mbt:55) of the streams opened from now
+ *                        on, so that the reference's shift_offsets can be reached in a few windows
+ *                        instead of after 2.1 GB (0 = the reference's value)
  *   "debug_drop_window_push"  test hook: k > 0 loses the k-th window hand-over of the next
  *                        multi-window launch, so that the bounded wait can be exercised */
 int flate_hip_set_option(flate_hip_ctx *ctx, const char *name, int64_t value);
@@ -144,9 +151,14 @@ int flate_hip_deflate_fast_batch(flate_hip_ctx *ctx, const uint8_t *in,
  *   n: a multiple of 65535 (whole windows) unless final; final != 0: any n (also 0), ends the
  *   stream with Writer::close's block (deflate.mbt:171-176).  in / out are HOST buffers;
  *   out_cap >= flate_hip_stream_bound(n).  Errors are sticky (Compressor.err, deflate.mbt:74):
- *   after a failed or a final write every further write fails.  The stream may be of any length
- *   (no 2 GiB limit here: the origin of its positions moves up as the reference's shift_offsets
- *   does, deflate-fast.mbt:366-389); one piece is < 1 GiB.  One wavefront compresses one
+ *   after a failed or a final write every further write fails.  The stream may be of any length;
+ *   one piece is < 1 GiB.  Where the reference's `cur` reaches buffer_reset (window 32 766 of a
+ *   Writer, then every 32 767 windows: deflate-fast.mbt:55,130-132) its shift_offsets runs
+ *   (:366-389), and so does this: in the default compat mode `prev` is empty, so the
+ *   table is CLEARED (:367-374) and the window starts without history; with FLATE_HIP_COMPAT_GO the
+ *   offsets move down and every distance stays what it was.  (Independently of that the origin of
+ *   the kernels' 32-bit positions moves up every "stream_rebase_bytes"; that changes no result.)
+ *   One wavefront compresses one
  *   stream: this is the reference's semantics for a long stream, not the engine's fast path
  *   (batches of streams are). */
 typedef struct flate_hip_stream flate_hip_stream;

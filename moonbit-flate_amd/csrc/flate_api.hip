@@ -103,6 +103,7 @@ struct flate_hip_ctx {
   uint32_t spin_limit = 8u << 20;
   uint32_t inject_drop_push = 0;  // test hook: the k-th window hand-over (1-based) is dropped
   uint64_t stream_rebase = 1ull << 30;  // flate_hip_stream: origin moved up past this many bytes
+  int64_t debug_buffer_reset = 0;       // test hook: buffer_reset (deflate-fast.mbt:55) of streams opened from now on
   hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
 };
 
@@ -163,7 +164,7 @@ struct StagePlan {
   uint32_t n_blocks = 0;
 };
 
-int make_plan(const uint64_t *in_off, uint32_t n, StagePlan &pl) {
+int make_plan(const uint64_t *in_off, uint32_t n, StagePlan &pl, uint32_t flags) {
   pl.n_streams = n;
   pl.chunk_base.resize((size_t)n + 1);
   pl.blk_base.resize((size_t)n + 1);
@@ -174,6 +175,12 @@ int make_plan(const uint64_t *in_off, uint32_t n, StagePlan &pl) {
     if (len >= 0x7ffe0000ull) return FLATE_HIP_E_TOO_LARGE;
     const uint64_t full = len / kMaxStoreBlockSize, r = len % kMaxStoreBlockSize;
     const uint64_t nch = full + (r >= (uint64_t)kSmallLzMin ? 1 : 0);
+    // The reference's `cur` reaches buffer_reset at a Writer's window 32 766 (deflate-fast.mbt:55,130):
+    // shift_offsets then CLEARS the table in MoonBit (`prev` is empty, :367-374).  Batch streams keep
+    // their table from start to end, so a stream with an LZ77 window that far in is refused here
+    // (flate_hip_stream_write follows the reference past that point); in Go's semantics the shift
+    // changes no distance and the 32-bit positions above are the only limit.
+    if (!(flags & FLATE_HIP_COMPAT_GO) && nch > 32766) return FLATE_HIP_E_TOO_LARGE;
     pl.chunk_base[i] = (uint32_t)chunks;
     pl.blk_base[i] = (uint32_t)blocks;
     if (nch == 1) {
@@ -383,6 +390,8 @@ int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, cons
       launch(c->d_ids32, (uint32_t)pl.ids32.size(), true, 1);
     }
   }
+  // (test hook: it loses one hand-over of THIS launch, not of every later one)
+  if (uq_units) c->inject_drop_push = 0;
   HIP_TRY(c, hipGetLastError());
   return FLATE_HIP_OK;
 }
@@ -410,7 +419,15 @@ const char *flate_hip_strerror(int code) {
 #ifndef FLATE_HIP_BUILD_ID
 #define FLATE_HIP_BUILD_ID "unknown"
 #endif
+#define FLATE_STR2(x) #x
+#define FLATE_STR(x) FLATE_STR2(x)
+#ifdef FLATE_EXPERIMENT_TABLE_BITS
+const char *flate_hip_build_id(void) {
+  return FLATE_HIP_BUILD_ID ";NOT-BIT-EXACT:table_bits=" FLATE_STR(FLATE_EXPERIMENT_TABLE_BITS);
+}
+#else
 const char *flate_hip_build_id(void) { return FLATE_HIP_BUILD_ID; }
+#endif
 
 const char *flate_hip_last_hip_error(const flate_hip_ctx *ctx) {
   return ctx ? ctx->hip_err.c_str() : "";
@@ -553,6 +570,8 @@ int flate_hip_set_option(flate_hip_ctx *c, const char *name, int64_t value) {
     c->stream_rebase = (uint64_t)value;
   } else if (k == "debug_drop_window_push" && value >= 0 && value <= 0x7fffffff) {
     c->inject_drop_push = (uint32_t)value;
+  } else if (k == "debug_buffer_reset" && value >= 0 && value <= 0x7fffffff) {
+    c->debug_buffer_reset = value;
 
   } else {
     return FLATE_HIP_E_INVALID;
@@ -599,7 +618,7 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
                           bool spliced, uint64_t *total_bytes) {
   HIP_TRY(c, hipSetDevice(c->device));
   StagePlan pl;
-  int rc = make_plan(in_off, n, pl);
+  int rc = make_plan(in_off, n, pl, flags);
   if (rc) return rc;
   const bool dev = (flags & FLATE_HIP_DEVICE_PTRS) != 0;
   const uint64_t in_bytes = in_off[n];
@@ -1005,7 +1024,7 @@ int flate_hip_deflate_fast_batch(flate_hip_ctx *c, const uint8_t *in, const uint
     if (n / per < G) G = n / per;
     if (G > 1) {
       StagePlan pl;  // validate the whole index first (the same checks as the one-call path)
-      const int rc = make_plan(in_off, n, pl);
+      const int rc = make_plan(in_off, n, pl, flags);
       if (rc) return rc;
       try {
         return deflate_host_pipelined(c, in, in_off, n, out, out_cap, out_off, flags, G);
@@ -1050,6 +1069,12 @@ struct flate_hip_stream {
   uint64_t abs = 0;        // bytes of the stream consumed so far (a multiple of 65535 until the end)
   uint64_t pos = 0;        // the same, counted from the stream's current origin (see rebase_at)
   uint64_t rebase_at = 1ull << 30;  // origin moved up when pos passes this (option stream_rebase_bytes)
+  // DeflateFast.cur as the reference counts it (deflate-fast.mbt:107,115,156): 65535 at the start,
+  // + the window's length after every encode; when it reaches buffer_reset (:55,130-132) shift_offsets
+  // runs -- in MoonBit `prev` is always empty, so that CLEARS the table (:367-374); in Go
+  // the offsets move down and every distance stays what it was
+  int64_t ref_cur = kMaxStoreBlockSize;
+  int64_t buffer_reset = 2147483647ll - 2 * kMaxStoreBlockSize;
   uint32_t carry_bits = 0; // bits of the last, incomplete output byte (0..7) ...
   uint8_t carry = 0;       // ... and their value
   bool closed = false;
@@ -1115,9 +1140,33 @@ int stream_write_impl(flate_hip_stream *st, const uint8_t *in, uint64_t n, bool 
     P.compat_go = (st->flags & FLATE_HIP_COMPAT_GO) ? 1u : 0u;
     P.status = (int *)c->d_status.p;
     P.spin_limit = c->spin_limit;
-    P.win0 = win0;
-    hipLaunchKernelGGL(lz77_resume_kernel, dim3(1), dim3(64), 0, c->stream, P, (uint16_t *)st->table.p,
-                       (uint32_t *)st->clock.p, nch, rebase);
+    // One launch per run of windows between two shift_offsets of the reference (one launch, except
+    // for the piece in which `cur` passes buffer_reset: window 32 766 of a Writer, then every 32 767).
+    const bool forgets = !(st->flags & FLATE_HIP_COMPAT_GO);
+    uint32_t k0 = 0;        // first window (of this piece) of the launch being collected
+    bool forget0 = false;   // ... and whether it starts on a cleared table
+    auto flush = [&](uint32_t k1) {
+      if (k1 == k0) return;
+      LzParams Q = P;
+      Q.win0 = win0 + k0;
+      Q.matches = P.matches + (size_t)k0 * kMatchCapPerChunk;  // the kernel indexes both by window - win0
+      Q.chunk_nmatch = P.chunk_nmatch + k0;
+      Q.chunk_ntok = P.chunk_ntok + k0;
+      hipLaunchKernelGGL(lz77_resume_kernel, dim3(1), dim3(64), 0, c->stream, Q, (uint16_t *)st->table.p,
+                         (uint32_t *)st->clock.p, k1 - k0, k0 == 0 ? rebase : 0u, forget0 ? 1u : 0u);
+    };
+    for (uint32_t k = 0; k < nch; ++k) {
+      if (st->ref_cur >= st->buffer_reset) {  // deflate-fast.mbt:130-132
+        st->ref_cur = kMaxMatchOffset + 1;    // :372,388
+        if (forgets) {
+          flush(k);
+          k0 = k;
+          forget0 = true;
+        }
+      }
+      st->ref_cur += k < full ? (int64_t)kMaxStoreBlockSize : (int64_t)r;  // :156
+    }
+    flush(nch);
   } else if (rebase) {
     st->pos += rebase;  // (nothing ran: the table still counts from the old origin)
   }
@@ -1201,6 +1250,7 @@ int flate_hip_stream_open(flate_hip_ctx *c, uint32_t flags, flate_hip_stream **o
   st->ctx = c;
   st->flags = flags;
   st->rebase_at = c->stream_rebase;
+  if (c->debug_buffer_reset > 0) st->buffer_reset = c->debug_buffer_reset;
   *out = st;
   return FLATE_HIP_OK;
 }
@@ -1237,7 +1287,7 @@ int flate_hip_lz77_matches(flate_hip_ctx *c, const uint8_t *in, const uint64_t *
   if (!c || !in_off || !n_chunks || !n_recs_cap) return FLATE_HIP_E_INVALID;
   c->hip_err.clear();
   StagePlan pl;
-  int rc = make_plan(in_off, n, pl);
+  int rc = make_plan(in_off, n, pl, flags);
   if (rc) return rc;
   *n_chunks = pl.n_chunks;
   *n_recs_cap = (uint64_t)pl.n_chunks * kMatchCapPerChunk;
@@ -1443,10 +1493,10 @@ int flate_hip_inflate_batch(flate_hip_ctx *c, const uint8_t *in, const uint64_t 
   if (n == 0) return FLATE_HIP_OK;
   for (uint32_t i = 0; i < n; ++i)
     if (in_off[i + 1] < in_off[i] || (!size_only && out_off[i + 1] < out_off[i])) return FLATE_HIP_E_INVALID;
-  if (size_only)
-    return inflate_common(c, in, in_off, n, nullptr, nullptr, out_len, status, err_off, flags, 0);
   for (uint32_t i = 0; i < n; ++i)
     if (in_off[i + 1] - in_off[i] >= 0x7ffe0000ull) return FLATE_HIP_E_TOO_LARGE;
+  if (size_only)
+    return inflate_common(c, in, in_off, n, nullptr, nullptr, out_len, status, err_off, flags, 0);
   // host pointers and a large batch: decode group g while g+1 is copied in and g-1 out
   if (!(flags & FLATE_HIP_DEVICE_PTRS) && c->host_groups > 1 &&
       in_off[n] - in_off[0] + out_off[n] - out_off[0] >= (64ull << 20)) {

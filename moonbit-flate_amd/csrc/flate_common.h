@@ -16,10 +16,14 @@
 
 namespace flate {
 
-#ifndef FLATE_EXPERIMENT_TABLE_BITS
-#define FLATE_EXPERIMENT_TABLE_BITS 14
+// deflate-fast.mbt:12.  A scaling probe may build the library with another table size
+// (-DFLATE_EXPERIMENT_TABLE_BITS=n: NOT bit-exact); such a build says so in flate_hip_build_id().
+#ifdef FLATE_EXPERIMENT_TABLE_BITS
+constexpr int kTableBits = FLATE_EXPERIMENT_TABLE_BITS;
+#else
+constexpr int kTableBits = 14;
+static_assert(kTableBits == 14, "table_bits of the reference");
 #endif
-constexpr int kTableBits = FLATE_EXPERIMENT_TABLE_BITS;  // deflate-fast.mbt:12 (14)
 constexpr int kTableSize = 1 << kTableBits;     // :15
 constexpr int kTableShift = 32 - kTableBits;    // :21
 constexpr int kMaxMatchOffset = 1 << 15;        // :40

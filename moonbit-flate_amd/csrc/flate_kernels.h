@@ -12,10 +12,14 @@ namespace flate {
 // counters of the overlapped entropy stage (flate_hip_ctx::d_done): at most this many sub-batches
 constexpr uint32_t kDoneCounters = 64;
 // device-side status words that the host turns into FLATE_HIP_E_INTERNAL with a message
-constexpr int kStatusUqTimeout = -8;     // uq_pop: the unit with my ticket was never pushed
-constexpr int kStatusGateTimeout = -9;   // wait_count_kernel: a sub-batch was never finished
-constexpr int kStatusBadIndex = -10;     // an index outside the scratch it addresses (never expected)
-constexpr int kStatusLanesLost = -11;    // a persistent loop is running without all 64 lanes
+// (a range of their own: no device-only word may alias a public FLATE_HIP_E_* code, which some status
+// words are -- FLATE_HIP_E_OUT_TOO_SMALL from the scan kernels -- and which a caller may be handed raw;
+// every value <= kStatusUqTimeout is an internal condition, the pack self-check's -(0x100000 + stream) too)
+constexpr int kStatusUqTimeout = -0x1001;    // uq_pop: the unit with my ticket was never pushed
+constexpr int kStatusGateTimeout = -0x1002;  // wait_count_kernel: a sub-batch was never finished
+constexpr int kStatusBadIndex = -0x1003;     // an index outside the scratch it addresses (never expected)
+constexpr int kStatusLanesLost = -0x1004;    // a persistent loop is running without all 64 lanes
+static_assert(kStatusUqTimeout < -64 && kStatusLanesLost > -0x100000, "device-only status words: their own range");
 
 struct LzParams {
   const uint8_t *in;
@@ -131,8 +135,10 @@ __global__ void lz77_guest_kernel(LzParams P);
 // `clock_io`; runs the nwin windows from P.win0 on
 // rebase != 0: every position the table and the clock hold is first moved down by that many bytes
 // (the stream's origin was moved up: what shift_offsets does for the reference, deflate-fast.mbt:366-389)
+// forget != 0: the first window of the launch starts on an empty table (shift_offsets with an empty
+// `prev`, deflate-fast.mbt:367-374: what the reference does in its default compat mode)
 __global__ void lz77_resume_kernel(LzParams P, uint16_t *table_io, uint32_t *clock_io, uint32_t nwin,
-                                   uint32_t rebase);
+                                   uint32_t rebase, uint32_t forget);
 __global__ void huff_hist_kernel(HuffParams P);
 __global__ void huff_code_kernel(HuffParams P);
 __global__ void huff_pack_kernel(HuffParams P);

@@ -994,12 +994,22 @@ __global__ __launch_bounds__(64) void lz77_guest_kernel(LzParams P) {
 // table offsets when `cur` nears 2^31 (shift_offsets, deflate-fast.mbt:366-389).  The slots hold
 // positions mod 2^16 (markers included), so every slot and the sweep clock move down by the same
 // amount and all distances stay what they were.
+// forget: the launch's first window starts on an EMPTY table -- what the reference's shift_offsets does
+// when `prev` is empty, which in MoonBit it always is (deflate-fast.mbt:367-374): every slot
+// becomes the marker that is out of range for the window's first position, exactly as a sweep that finds
+// every slot too old would leave it.
 __global__ __launch_bounds__(64) void lz77_resume_kernel(LzParams P, uint16_t *table_io, uint32_t *clock_io,
-                                                          uint32_t nwin, uint32_t rebase) {
+                                                          uint32_t nwin, uint32_t rebase, uint32_t forget) {
   __shared__ uint16_t table[kTableSize];
   const int lane = threadIdx.x;
   uint32_t clock = 0;
-  if (P.win0 != 0) {
+  if (P.win0 != 0 && forget) {
+    const uint32_t W = P.win0 * (uint32_t)kMaxStoreBlockSize;
+    const uint32_t fill = ((W - kMarkerBack + 1u) & 0xffffu) * 0x10001u;
+    uint4 *dst = reinterpret_cast<uint4 *>(table);
+    for (int i = lane; i < (int)(kTableSize * sizeof(uint16_t) / 16); i += 64) dst[i] = make_uint4(fill, fill, fill, fill);
+    clock = W + kSweepEvery;
+  } else if (P.win0 != 0) {
     const uint4 *src = reinterpret_cast<const uint4 *>(table_io);
     uint4 *dst = reinterpret_cast<uint4 *>(table);
     for (int i = lane; i < (int)(kTableSize * sizeof(uint16_t) / 16); i += 64) dst[i] = src[i];

@@ -109,6 +109,13 @@ orc_deflate_fast *orc_df_new(int compat) {
 void orc_df_free(orc_deflate_fast *e) { free(e); }
 int32_t orc_df_cur(const orc_deflate_fast *e) { return e->cur; }
 
+/* Test hook (not in the reference): buffer_reset (deflate-fast.mbt:55) is reached after 32 766
+ * windows of one Writer, about 2.1 GB; the tests lower it so that the shift_offsets branches run
+ * within a few windows.  0 = the reference's value.  Process-wide; set before the encoders run. */
+static volatile int32_t test_buffer_reset = 0;
+void orc_test_set_buffer_reset(int32_t v) { test_buffer_reset = v; }
+static int32_t buffer_reset(void) { return test_buffer_reset ? test_buffer_reset : ORC_BUFFER_RESET; }
+
 /* deflate-fast.mbt:366-389 */
 static void shift_offsets(orc_deflate_fast *e) {
   if (e->prev_len == 0) {
@@ -131,7 +138,7 @@ static void shift_offsets(orc_deflate_fast *e) {
 void orc_df_reset(orc_deflate_fast *e) {
   e->prev_len = 0;
   e->cur += ORC_MAX_MATCH_OFFSET;
-  if (e->cur >= ORC_BUFFER_RESET) shift_offsets(e);
+  if (e->cur >= buffer_reset()) shift_offsets(e);
 }
 
 /* deflate-fast.mbt:273-279 */
@@ -191,7 +198,7 @@ static int emit_remainder(orc_deflate_fast *e, uint32_t *dst, int ntok,
 /* deflate-fast.mbt:123-270 */
 int orc_df_encode(orc_deflate_fast *e, uint32_t *dst, int ntok, const uint8_t *src,
                   int n) {
-  if (e->cur >= ORC_BUFFER_RESET) shift_offsets(e); /* :130 */
+  if (e->cur >= buffer_reset()) shift_offsets(e); /* :130 */
 
   if (n < ORC_MIN_NON_LITERAL_BLOCK_SIZE) { /* :136-140 */
     e->cur += ORC_MAX_STORE_BLOCK_SIZE;

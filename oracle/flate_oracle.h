@@ -85,6 +85,9 @@ int orc_df_encode(orc_deflate_fast *e, uint32_t *dst, int ntok,
                   const uint8_t *src, int n);
 void orc_df_reset(orc_deflate_fast *e);
 int32_t orc_df_cur(const orc_deflate_fast *e);
+/* Test hook, not in the reference: lowers buffer_reset (deflate-fast.mbt:55, reached after
+ * 32 766 windows of one Writer) for every encoder of this process; 0 restores the real value. */
+void orc_test_set_buffer_reset(int32_t v);
 
 /* ---- whole-stream encode: Writer::new + write(...)* + close ---- */
 /* sizes[0..nwrites) are the byte counts of successive Writer::write calls

@@ -63,6 +63,7 @@ def lib():
         L.orc_df_reset.argtypes = [C.c_void_p]
         L.orc_df_cur.argtypes = [C.c_void_p]
         L.orc_df_cur.restype = C.c_int32
+        L.orc_test_set_buffer_reset.argtypes = [C.c_int32]
         L.orc_huffman_generate.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_last_blocks.argtypes = [C.POINTER(BlockInfo), C.c_int]
         L.orc_last_blocks.restype = C.c_int
@@ -173,6 +174,11 @@ def deflate_spliced(in_buf, in_off, compat=COMPAT_MOONBIT):
     if rc != 0:
         raise RuntimeError("oracle spliced deflate failed: %d" % rc)
     return out[:out_len.value].tobytes(), bit_off
+
+
+def set_buffer_reset(v):
+    """Test hook: buffer_reset (deflate-fast.mbt:55) of every encoder of this process; 0 = the real one."""
+    lib().orc_test_set_buffer_reset(int(v))
 
 
 class DeflateFast:

@@ -122,3 +122,47 @@ def test_long_stream_moves_its_origin(oracle):
             assert got == want, (kind, go)
     finally:
         e.close()
+
+
+def test_shift_offsets_as_the_reference_behaves(oracle):
+    # deflate-fast.mbt:130-132,366-389: at window 32 766 of a Writer (2.1 GB in) `cur` reaches
+    # buffer_reset and shift_offsets runs: MoonBit clears the table there (`prev` is empty),
+    # Go keeps every distance.  With buffer_reset lowered on both sides (test hooks) the shifts fall
+    # on windows 2, 5 and 8 of an 11-window stream; pieces are cut so that a shift falls on the
+    # first, a middle and the last window of a piece, and the origin of the kernels' positions moves
+    # (stream_rebase_bytes) in the same stream.
+    e = flate.FlateEngine(0)
+    try:
+        e.set_option("debug_buffer_reset", 3 * W)
+        oracle.set_buffer_reset(3 * W)
+        for rebase in (1 << 30, 2 * W):
+            e.set_option("stream_rebase_bytes", rebase)
+            for kind, go in (("text", False), ("text", True), ("period", False), ("runs", False), ("low", True)):
+                n = 11 * W + 3000
+                data, _ = make_streams([(kind, n)], seed=43)
+                data = data[:n]
+                want = oracle.deflate(data, compat=oracle.COMPAT_GO if go else 0)
+                for cuts in ([2, 1, 3, 2, 3], [1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1], [11], [3, 5]):
+                    got, _ = _pieces(e, data, cuts, compat_go=go)
+                    assert got == want, (kind, go, cuts, rebase)
+        # and the hook changes the stream in MoonBit mode only
+        oracle.set_buffer_reset(0)
+        data, _ = make_streams([("text", 4 * W)], seed=43)
+        data = data[:4 * W]
+        got, _ = _pieces(e, data, [4])
+        assert got != oracle.deflate(data)
+        got_go, _ = _pieces(e, data, [4], compat_go=True)
+        assert got_go == oracle.deflate(data, compat=oracle.COMPAT_GO)
+    finally:
+        oracle.set_buffer_reset(0)
+        e.close()
+
+
+def test_batch_refuses_a_stream_that_reaches_buffer_reset(eng):
+    # a batch stream keeps its table from start to end: one with an LZ77 window at index 32 766 is
+    # refused (E_TOO_LARGE) rather than compressed differently from the reference
+    big = 32766 * W + 128
+    off = np.array([0, big], np.uint64)
+    with pytest.raises(flate.FlateError) as ei:
+        eng.deflate_batch(np.zeros(16, np.uint8), off, out_cap=64)
+    assert ei.value.code == -6

@@ -274,3 +274,42 @@ def test_oracle_inflate_batch_matches_single_stream_decoder(oracle):
         assert olen[i] == len(res)
         assert bytes(out[int(ooff[i]):int(ooff[i]) + len(res)]) == res
     assert list(status[:5]) == [0] * 5 and status[5] == oracle.E_UNEXPECTED_EOF and status[6] == oracle.E_CORRUPT
+
+
+def test_shift_offsets_branches_with_lowered_buffer_reset(oracle):
+    """deflate-fast.mbt:130-132,366-389: when `cur` reaches buffer_reset (window 32 766 of a Writer)
+    shift_offsets runs.  MoonBit's `prev` is always empty, so the table is CLEARED
+    (:367-374): the window after it starts without history.  In Go's semantics `prev` holds the last
+    window and the offsets only move down: no distance changes.  The test hook lowers buffer_reset
+    so that both branches run within a few windows."""
+    from util import make_streams, raw_inflate
+    W = 65535
+    n = 8 * W + 2000
+    data, _ = make_streams([("text", n)], seed=31)
+    data = data[:n]
+    plain = {c: oracle.deflate(data, compat=c) for c in (oracle.COMPAT_MOONBIT, oracle.COMPAT_GO)}
+    try:
+        oracle.set_buffer_reset(3 * W)  # cur = 65535 (k + 1) at window k: shifts at windows 2, 5, 8
+        # `cur` after the shift is max_match_offset + 1 (:372,388)
+        df = oracle.DeflateFast(oracle.COMPAT_MOONBIT)
+        curs = []
+        for k in range(7):
+            df.encode(data[k * W:(k + 1) * W])
+            curs.append(df.cur)
+        assert curs == [2 * W, 3 * W, 32769 + W, 32769 + 2 * W, 32769 + 3 * W, 32769 + W, 32769 + 2 * W]
+        low = {c: oracle.deflate(data, compat=c) for c in (oracle.COMPAT_MOONBIT, oracle.COMPAT_GO)}
+    finally:
+        oracle.set_buffer_reset(0)
+    for c in low:
+        assert raw_inflate(low[c]) == data.tobytes()
+    # Go: the shift is invisible.  MoonBit: windows 2 and 5 lose the candidates of the window before
+    assert low[oracle.COMPAT_GO] == plain[oracle.COMPAT_GO]
+    assert low[oracle.COMPAT_MOONBIT] != plain[oracle.COMPAT_MOONBIT]
+    # the first two windows' blocks are untouched by the first shift
+    _, blocks_plain = oracle.deflate(data, with_blocks=True)
+    try:
+        oracle.set_buffer_reset(3 * W)
+        _, blocks_low = oracle.deflate(data, with_blocks=True)
+    finally:
+        oracle.set_buffer_reset(0)
+    assert blocks_low[:2] == blocks_plain[:2] and blocks_low[2][2] != blocks_plain[2][2]
