@@ -41,7 +41,8 @@ typedef struct flate_hip_ctx flate_hip_ctx;
                                            write such a stream with flate_hip_stream_write, which follows
                                            the reference through shift_offsets                        */
 #define FLATE_HIP_E_UNEXPECTED_EOF (-7) /* inflate: err_unexpected_eof (inflate.mbt:781) */
-#define FLATE_HIP_E_AGAIN (-9)          /* flate_hip_gather_end: a shard outgrew the agreed pad; the
+#define FLATE_HIP_E_AGAIN (-9)          /* flate_hip_gather_end: a shard outgrew the agreed pad, or a
+                                           rank holds more streams than the plan allows for; the
                                            plan has been raised on every rank: repeat this batch
                                            with flate_hip_gather_compressed                      */
 #define FLATE_HIP_E_INTERNAL (-8)       /* encoder self-check failed (the reference abort()s on its
@@ -266,7 +267,13 @@ int flate_hip_gather_compressed(flate_hip_comm *comm, const uint8_t *local, uint
  * begin returns at once: the exchange starts when the work queued so far on the ctx's stream
  * (the compression that wrote local) is done and runs on the communicator's own stream, beside
  * the next batch's compression.  local and out must stay untouched until end, which waits for
- * the exchange and fills the index; FLATE_HIP_E_AGAIN = a shard outgrew the pad (raised now). */
+ * the exchange and fills the index; FLATE_HIP_E_AGAIN = a shard outgrew the pad or a rank holds more
+ * streams than the plan's max_streams (both raised now, on every rank alike: the condition travels
+ * through the exchange itself, no rank refuses alone).  begin's own refusals -- no plan
+ * (FLATE_HIP_E_INVALID), out_cap < world * pad (FLATE_HIP_E_OUT_TOO_SMALL) -- depend only on the plan
+ * and on out_cap, which the caller must keep EQUAL on all ranks: then they too are taken by every
+ * rank or by none.  The metadata copies use pinned host memory of the communicator, so begin does not
+ * wait for the compression queued in front of it (tests/test_gather_abi.py times that). */
 int flate_hip_gather_begin(flate_hip_comm *comm, const uint8_t *local, uint64_t local_cap,
                            const uint64_t *local_off, uint32_t k, uint8_t *out, uint64_t out_cap);
 int flate_hip_gather_end(flate_hip_comm *comm, uint64_t *stream_off, uint64_t *stream_len,

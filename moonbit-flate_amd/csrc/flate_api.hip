@@ -411,7 +411,7 @@ const char *flate_hip_strerror(int code) {
     case FLATE_HIP_E_TOO_LARGE: return "stream too large";
     case FLATE_HIP_E_UNEXPECTED_EOF: return "unexpected EOF";
     case FLATE_HIP_E_INTERNAL: return "internal error: encoder self-check failed";
-    case FLATE_HIP_E_AGAIN: return "a shard outgrew the agreed pad: repeat this batch with the blocking exchange";
+    case FLATE_HIP_E_AGAIN: return "a shard outgrew the agreed plan (pad or stream count): repeat this batch with the blocking exchange";
     default: return "unknown error";
   }
 }

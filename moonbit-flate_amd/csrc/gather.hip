@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -46,9 +47,20 @@ Rccl *rccl() {
   static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
+    // FLATE_HIP_TEST_TRANSPORT = path of a library with the same nine entry points: the tests'
+    // rehearsal transport (tests/rehearsal_transport/, ranks as processes on ONE GPU exchanging
+    // through host shared memory), so that the multi-rank branches below can run on a one-GPU box.
+    // It is never part of this library.
+    if (const char *alt = getenv("FLATE_HIP_TEST_TRANSPORT")) {
+      r.h = dlopen(alt, RTLD_NOW | RTLD_LOCAL);
+      if (!r.h) {
+        r.err = std::string("cannot load FLATE_HIP_TEST_TRANSPORT: ") + dlerror();
+        return;
+      }
+    }
     for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
       if (r.h) break;
+      r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     }
     if (!r.h) {
       r.err = std::string("cannot load RCCL: ") + dlerror();
@@ -93,7 +105,10 @@ struct flate_hip_comm {
   hipStream_t gstream = nullptr;
   hipEvent_t ev_ready = nullptr, ev_done = nullptr;
   Buf d_meta, d_metas, d_stage;
-  std::vector<uint64_t> h_meta, h_metas;
+  // landing pads of the metadata copies: PINNED host memory, so that the asynchronous copies of
+  // flate_hip_gather_begin really are asynchronous (a copy to or from pageable memory makes the
+  // calling thread wait for everything queued in front of it: the compression and the exchange)
+  Buf h_meta, h_metas;
   // the gather in flight (begin .. end)
   bool in_flight = false;
   uint32_t fl_mode = 0;
@@ -131,6 +146,16 @@ int grow(flate_hip_comm *cm, Buf &b, size_t bytes) {
   return FLATE_HIP_OK;
 }
 
+int grow_pinned(flate_hip_comm *cm, Buf &b, size_t bytes) {
+  if (bytes <= b.cap) return FLATE_HIP_OK;
+  if (b.p) G_HIP(cm, hipHostFree(b.p));
+  b.p = nullptr;
+  b.cap = 0;
+  G_HIP(cm, hipHostMalloc(&b.p, bytes + (bytes >> 2) + 256, hipHostMallocDefault));
+  b.cap = bytes + (bytes >> 2) + 256;
+  return FLATE_HIP_OK;
+}
+
 uint64_t round_up(uint64_t v, uint64_t to) {
   const uint64_t r = (v + to - 1) / to * to;
   return r < to ? to : r;
@@ -146,11 +171,13 @@ int check_offsets(const uint64_t *off, uint32_t k) {
 // metadata of one rank: {payload bytes, stream count, off[0 .. kmax]} as u64
 size_t meta_words(uint32_t kmax) { return (size_t)kmax + 3; }
 
-void fill_meta(std::vector<uint64_t> &m, const uint64_t *local_off, uint32_t k, uint32_t kmax) {
-  m.assign(meta_words(kmax), 0);
+// (k may exceed kmax in the overlapped form: the count travels, the offsets that do not fit are left
+// out, and every rank then raises the plan and repeats -- see resolve)
+void fill_meta(uint64_t *m, const uint64_t *local_off, uint32_t k, uint32_t kmax) {
+  memset(m, 0, meta_words(kmax) * 8);
   m[0] = local_off[k];
   m[1] = k;
-  for (uint32_t i = 0; i <= k; ++i) m[2 + i] = local_off[i];
+  for (uint32_t i = 0; i <= k && i <= kmax; ++i) m[2 + i] = local_off[i];
 }
 
 // issue the metadata all-gather and the payload exchange on `s`; the sticky plan is final here
@@ -163,8 +190,11 @@ int issue(flate_hip_comm *cm, const uint8_t *local, uint64_t local_cap, const ui
   const size_t mw = meta_words(cm->kmax);
   if ((rc = grow(cm, cm->d_meta, mw * 8))) return rc;
   if ((rc = grow(cm, cm->d_metas, mw * 8 * (size_t)W))) return rc;
-  fill_meta(cm->h_meta, local_off, k, cm->kmax);
-  G_HIP(cm, hipMemcpyAsync(cm->d_meta.p, cm->h_meta.data(), mw * 8, hipMemcpyHostToDevice, s));
+  if ((rc = grow_pinned(cm, cm->h_meta, mw * 8))) return rc;
+  if ((rc = grow_pinned(cm, cm->h_metas, mw * 8 * (size_t)W))) return rc;
+  // (h_meta is free again: at most one exchange is in flight and the last one has been waited for)
+  fill_meta((uint64_t *)cm->h_meta.p, local_off, k, cm->kmax);
+  G_HIP(cm, hipMemcpyAsync(cm->d_meta.p, cm->h_meta.p, mw * 8, hipMemcpyHostToDevice, s));
   G_NCCL(cm, R->AllGather(cm->d_meta.p, cm->d_metas.p, mw, ncclUint64, cm->comm, s));
   if (mode == FLATE_HIP_GATHER_ALLGATHER) {
     const uint8_t *src = local;
@@ -176,12 +206,16 @@ int issue(flate_hip_comm *cm, const uint8_t *local, uint64_t local_cap, const ui
     G_NCCL(cm, R->AllGather(src, out, cm->pad, ncclUint8, cm->comm, s));
   } else {
     G_NCCL(cm, R->GroupStart());
-    for (int r = 0; r < W; ++r) {
+    ncclResult_t bad = ncclSuccess;  // (a group that was started is always ended)
+    for (int r = 0; r < W && bad == ncclSuccess; ++r) {
       if (r == cm->rank) continue;
-      if (clen) G_NCCL(cm, R->Send(local, clen, ncclUint8, r, cm->comm, s));
-      if (peer_bytes[r]) G_NCCL(cm, R->Recv(out + rank_base[r], peer_bytes[r], ncclUint8, r, cm->comm, s));
+      if (clen) bad = R->Send(local, clen, ncclUint8, r, cm->comm, s);
+      if (bad == ncclSuccess && peer_bytes[r])
+        bad = R->Recv(out + rank_base[r], peer_bytes[r], ncclUint8, r, cm->comm, s);
     }
-    G_NCCL(cm, R->GroupEnd());
+    const ncclResult_t ended = R->GroupEnd();
+    G_NCCL(cm, bad);
+    G_NCCL(cm, ended);
     if (clen)
       G_HIP(cm, hipMemcpyAsync(out + rank_base[cm->rank], local, clen, hipMemcpyDeviceToDevice, s));
   }
@@ -193,16 +227,22 @@ int resolve(flate_hip_comm *cm, uint32_t mode, uint64_t *stream_off, uint64_t *s
             uint64_t *total_streams, bool *overflow) {
   const int W = cm->world;
   const size_t mw = meta_words(cm->kmax);
-  const uint64_t *m = cm->h_metas.data();
-  uint64_t total = 0, max_bytes = 0;
+  const uint64_t *m = (const uint64_t *)cm->h_metas.p;
+  uint64_t total = 0, max_bytes = 0, max_k = 0;
   for (int r = 0; r < W; ++r) {
     total += m[r * mw + 1];
     if (m[r * mw] > max_bytes) max_bytes = m[r * mw];
+    if (m[r * mw + 1] > max_k) max_k = m[r * mw + 1];
   }
   if (total_streams) *total_streams = total;
-  *overflow = mode == FLATE_HIP_GATHER_ALLGATHER && max_bytes > cm->pad;
-  if (*overflow) {  // every rank sees the same metadata, so every rank raises the pad alike
-    cm->pad = round_up(max_bytes, cm->pad_to);
+  // A shard that outgrew the pad, or a rank with more streams than the metadata block holds: both are
+  // data-dependent, so neither may be refused by one rank alone (its peers would wait in the
+  // collective).  Every rank has taken part, every rank sees the same metadata, every rank raises
+  // the plan alike and reports FLATE_HIP_E_AGAIN.
+  *overflow = (mode == FLATE_HIP_GATHER_ALLGATHER && max_bytes > cm->pad) || max_k > cm->kmax;
+  if (*overflow) {
+    if (max_bytes > cm->pad) cm->pad = round_up(max_bytes, cm->pad_to);
+    if (max_k > cm->kmax) cm->kmax = (uint32_t)max_k;
     return FLATE_HIP_E_AGAIN;
   }
   if (total > index_cap || !stream_off || !stream_len) return total ? FLATE_HIP_E_OUT_TOO_SMALL : FLATE_HIP_OK;
@@ -311,6 +351,8 @@ void flate_hip_comm_destroy(flate_hip_comm *cm) {
   if (cm->owned && cm->comm) (void)rccl()->CommDestroy(cm->comm);
   for (Buf *b : {&cm->d_meta, &cm->d_metas, &cm->d_stage})
     if (b->p) (void)hipFree(b->p);
+  for (Buf *b : {&cm->h_meta, &cm->h_metas})
+    if (b->p) (void)hipHostFree(b->p);
   if (cm->ev_ready) (void)hipEventDestroy(cm->ev_ready);
   if (cm->ev_done) (void)hipEventDestroy(cm->ev_done);
   if (cm->gstream) (void)hipStreamDestroy(cm->gstream);
@@ -368,8 +410,7 @@ int flate_hip_gather_compressed(flate_hip_comm *cm, const uint8_t *local, uint64
   // 2. metadata + payload
   if ((rc = issue(cm, local, local_cap, local_off, k, out, mode, bytes.data(), base.data(), s))) return rc;
   const size_t mw = meta_words(cm->kmax);
-  cm->h_metas.resize(mw * (size_t)W);
-  G_HIP(cm, hipMemcpyAsync(cm->h_metas.data(), cm->d_metas.p, mw * 8 * (size_t)W, hipMemcpyDeviceToHost, s));
+  G_HIP(cm, hipMemcpyAsync(cm->h_metas.p, cm->d_metas.p, mw * 8 * (size_t)W, hipMemcpyDeviceToHost, s));
   G_HIP(cm, hipStreamSynchronize(s));
   bool overflow = false;
   return resolve(cm, mode, stream_off, stream_len, index_cap, total_streams, &overflow);
@@ -385,8 +426,12 @@ int flate_hip_gather_begin(flate_hip_comm *cm, const uint8_t *local, uint64_t lo
   if (rc) return rc;
   const uint64_t clen = local_off[k];
   if ((clen && !local) || local_cap < clen) return FLATE_HIP_E_INVALID;
-  // a plan must exist (one blocking call, or flate_hip_comm_set_plan on every rank) and hold this batch
-  if (cm->pad == 0 || cm->kmax == 0 || k > cm->kmax) return FLATE_HIP_E_INVALID;
+  // A plan must exist (one blocking call, or flate_hip_comm_set_plan on every rank).  The two
+  // refusals here depend on the plan, the world size and out_cap only -- values the caller must keep
+  // equal on all ranks -- so every rank takes the same branch and nobody is left in the collective.
+  // What depends on the data (a shard larger than the pad, more streams than the plan holds) goes
+  // through the exchange and comes back from flate_hip_gather_end as FLATE_HIP_E_AGAIN on every rank.
+  if (cm->pad == 0 || cm->kmax == 0) return FLATE_HIP_E_INVALID;
   if (out_cap < (uint64_t)cm->world * cm->pad) return FLATE_HIP_E_OUT_TOO_SMALL;
   cm->err.clear();
   G_HIP(cm, hipSetDevice(flate::ctx_device(cm->ctx)));
@@ -395,8 +440,7 @@ int flate_hip_gather_begin(flate_hip_comm *cm, const uint8_t *local, uint64_t lo
   if ((rc = issue(cm, local, local_cap, local_off, k, out, FLATE_HIP_GATHER_ALLGATHER, nullptr, nullptr, cm->gstream)))
     return rc;
   const size_t mw = meta_words(cm->kmax);
-  cm->h_metas.resize(mw * (size_t)cm->world);
-  G_HIP(cm, hipMemcpyAsync(cm->h_metas.data(), cm->d_metas.p, mw * 8 * (size_t)cm->world, hipMemcpyDeviceToHost,
+  G_HIP(cm, hipMemcpyAsync(cm->h_metas.p, cm->d_metas.p, mw * 8 * (size_t)cm->world, hipMemcpyDeviceToHost,
                            cm->gstream));
   G_HIP(cm, hipEventRecord(cm->ev_done, cm->gstream));
   cm->in_flight = true;

@@ -242,8 +242,9 @@ class NativeComm:
             out = torch.empty(max(need, 16), dtype=torch.uint8, device=local_buf.device)
         return out
 
-    def gather(self, local_buf, local_off, out=None, mode="allgather", total_streams_cap=None):
-        """Blocking exchange (flate_hip_gather_compressed)."""
+    def gather(self, local_buf, local_off, out=None, mode="allgather", total_streams_cap=None, claim_out_cap=None):
+        """Blocking exchange (flate_hip_gather_compressed).  claim_out_cap: the capacity to report for
+        `out` instead of its size (tests: FLATE_HIP_E_OUT_TOO_SMALL must come back on EVERY rank)."""
         import ctypes as C
         local_off = np.ascontiguousarray(local_off, dtype=np.uint64)
         k = local_off.size - 1
@@ -255,8 +256,8 @@ class NativeComm:
         total = C.c_uint64(0)
         self._eng._check(self._L.flate_hip_gather_compressed(
             self._comm, local_buf.data_ptr(), local_buf.numel(), local_off.ctypes.data, k,
-            out.data_ptr(), out.numel(), off.ctypes.data, length.ctypes.data, cap, C.byref(total),
-            MODES[mode]))
+            out.data_ptr(), out.numel() if claim_out_cap is None else int(claim_out_cap),
+            off.ctypes.data, length.ctypes.data, cap, C.byref(total), MODES[mode]))
         t = int(total.value)
         return NativeGathered(out, off[:t], length[:t], self.plan()[0])
 
@@ -270,7 +271,8 @@ class NativeComm:
 
     def end(self, total_streams_cap):
         """Waits for the exchange begun last; returns NativeGathered, or None if a shard outgrew the
-        pad (FLATE_HIP_E_AGAIN: the plan has been raised, repeat the batch with gather())."""
+        pad or a rank holds more streams than the plan allows (FLATE_HIP_E_AGAIN on every rank: the
+        plan has been raised, repeat the batch with gather())."""
         import ctypes as C
         cap = int(total_streams_cap)
         off, length = np.zeros(cap, np.uint64), np.zeros(cap, np.uint64)

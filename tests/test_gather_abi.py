@@ -2,9 +2,16 @@
 
 CPU: the layout arithmetic (flate_hip_gather_layout) against the rules of shard.py's torch form.
 GPU (one card): a one-rank RCCL communicator -- the index arithmetic, both exchange forms, the
-overlapped begin/end pair, the overflow of the sticky pad.  More ranks need more GPUs; the
-multi-rank control flow is rehearsed with gloo in test_distributed_cpu.py."""
+overlapped begin/end pair (and that begin does not wait for the work queued in front of it), the
+overflow of the sticky plan -- and TWO ranks as two processes on the one card over the tests'
+rehearsal transport (tests/rehearsal_transport/: RCCL refuses two ranks on one device), which is
+where the multi-rank branches of csrc/gather.hip run: peer sizes, rank_base placement, the grouped
+send/receive loop, refusals and plan overflows decided alike on every rank."""
 import importlib
+import os
+import subprocess
+import sys
+import time
 
 import numpy as np
 import pytest
@@ -67,10 +74,100 @@ def test_one_rank_communicator_both_forms_and_overlap(oracle):
         assert comm.end(n) is None and comm.plan()[0] >= int(bcoff[-1])
         g = comm.gather(bcomp, bcoff)
         assert torch.equal(g.buf[:int(bcoff[-1])], bcomp[:int(bcoff[-1])])
-        # more streams than the plan allows is refused before anything is issued
-        with pytest.raises(flate.FlateError):
-            comm.begin(comp, np.zeros(n + 50, np.uint64), out2)
+        # more streams than the plan allows: not refused by this rank alone (its peers would wait in
+        # the collective) -- the exchange runs, end reports E_AGAIN and the plan holds them afterwards
+        nk = comm.plan()[1] + 50
+        small = flate.synth("text", nk, 200, first_stream=9)
+        kcomp, kcoff = eng.deflate_batch(torch.from_numpy(small).cuda(), flate.uniform_offsets(nk, 200))
+        comm.begin(kcomp, kcoff, out2)
+        assert comm.end(2 * nk) is None and comm.plan()[1] == nk
+        comm.begin(kcomp, kcoff, out2)
+        g = comm.end(2 * nk)
+        assert g is not None and g.off.size == nk and torch.equal(g.buf[:int(kcoff[-1])], kcomp[:int(kcoff[-1])])
+        # without a plan begin refuses (a rank-independent condition)
+        comm2 = shard.NativeComm(eng, 0, 1)
+        try:
+            with pytest.raises(flate.FlateError):
+                comm2.begin(comp, coff, out2)
+        finally:
+            comm2.close()
     finally:
         if comm is not None:
             comm.close()
         eng.close()
+
+
+@pytest.mark.gpu
+def test_begin_returns_before_the_work_in_front_of_it_is_done():
+    """flate_hip_gather_begin is documented to return at once: the exchange waits -- on the GPU, behind an
+    event -- for what is queued on the ctx's stream.  Its metadata copies therefore use pinned host memory
+    (an asynchronous copy to or from pageable memory makes the calling thread wait for the stream)."""
+    import torch
+    n, blen = 64, 30000
+    data = flate.synth("text", n, blen, first_stream=11)
+    off = flate.uniform_offsets(n, blen)
+    eng = flate.FlateEngine(0)
+    comm = None
+    try:
+        comp, coff = eng.deflate_batch(torch.from_numpy(data).cuda(), off)
+        comm = shard.NativeComm(eng, 0, 1)
+        g0 = comm.gather(comp, coff)  # makes the plan
+        side = torch.cuda.Stream()
+        eng.use_stream(side.cuda_stream)
+        # how long does the spin kernel take per tick on this box?
+        t0 = time.perf_counter()
+        with torch.cuda.stream(side):
+            torch.cuda._sleep(2_000_000)
+        side.synchronize()
+        per_tick = (time.perf_counter() - t0) / 2_000_000
+        ticks = int(min(max(0.5 / max(per_tick, 1e-10), 1e6), 4e9))  # about half a second
+        out = torch.zeros(comm.plan()[0] + 64, dtype=torch.uint8, device="cuda")
+        done = torch.cuda.Event()
+        with torch.cuda.stream(side):
+            torch.cuda._sleep(ticks)
+            done.record(side)
+        t0 = time.perf_counter()
+        comm.begin(comp, coff, out)
+        dt = time.perf_counter() - t0
+        still_running = not done.query()
+        g = comm.end(n)
+        assert g is not None and torch.equal(g.buf[:int(coff[-1])], g0.buf[:int(coff[-1])])
+        assert still_running and dt < 0.25, (dt, still_running, per_tick, ticks)
+    finally:
+        eng.use_stream(None)
+        if comm is not None:
+            comm.close()
+        eng.close()
+
+
+def _rehearsal_transport():
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rehearsal_transport")
+    src, lib = os.path.join(here, "rehearsal_rccl.cpp"), os.path.join(here, "librehearsal_rccl.so")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+        subprocess.check_call(["g++", "-O1", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", src,
+                               "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-lpthread", "-Wl,-rpath,/opt/rocm/lib",
+                               "-o", lib])
+    return lib
+
+
+def test_rehearsal_transport_builds_and_exports_what_gather_binds():
+    import ctypes as C
+    L = C.CDLL(_rehearsal_transport())
+    for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclAllGather", "ncclSend", "ncclRecv",
+                 "ncclGroupStart", "ncclGroupEnd", "ncclGetErrorString"):
+        assert hasattr(L, name), name
+
+
+@pytest.mark.gpu
+def test_two_ranks_through_the_c_abi_exchange_on_one_card():
+    """tests/tools/native_gather_ranks.py with two processes: both exchange forms, the overlapped pair,
+    a pad overflow and a stream-count overflow (E_AGAIN on both ranks, plans raised alike), an `out` that
+    is too small on one rank (E_OUT_TOO_SMALL on both), every gathered stream checked against the oracle."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FLATE_HIP_TEST_TRANSPORT=_rehearsal_transport(), FLATE_REHEARSAL_TIMEOUT_S="90")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "native_gather_ranks.py"), "2"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "native gather ok: 2 ranks" in out.stdout
