@@ -128,6 +128,19 @@ const char *flate_hip_build_id(void);
 /* Text of the last HIP runtime error seen by this ctx ("" if none). */
 const char *flate_hip_last_hip_error(const flate_hip_ctx *ctx);
 
+/* -- host buffers ---------------------------------------------------------------
+ * The reference's Writer / Reader are handed host memory (writer.mbt:45, inflate.mbt:382); a host-pointer
+ * call copies it over PCIe inside the call.  From PAGEABLE memory every such copy is staged through the
+ * runtime's own bounce buffers; from page-locked memory it is one DMA transfer at the link's rate.  A
+ * caller that keeps its buffers across calls registers them once (the page-locking itself costs about
+ * as much as one copy of the buffer, and touches every page: a fresh output buffer is also faulted in
+ * here instead of inside the first call) or lets the library allocate page-locked memory.  The calls
+ * themselves are unchanged: they recognise registered ranges by address. */
+int flate_hip_host_register(flate_hip_ctx *ctx, void *ptr, size_t bytes);
+int flate_hip_host_unregister(flate_hip_ctx *ctx, void *ptr);
+int flate_hip_host_alloc(flate_hip_ctx *ctx, size_t bytes, void **ptr);
+int flate_hip_host_free(flate_hip_ctx *ctx, void *ptr);
+
 /* -- encode ---------------------------------------------------------------------
  * Upper bound of the compressed size of one stream of in_len bytes. */
 size_t flate_hip_deflate_bound(size_t in_len);
@@ -193,6 +206,35 @@ int flate_hip_inflate_batch(flate_hip_ctx *ctx, const uint8_t *in, const uint64_
                             uint32_t n_streams, uint8_t *out, const uint64_t *out_off,
                             uint64_t *out_len, int32_t *status, int64_t *err_off,
                             uint32_t flags);
+
+/* ONE stream decoded in pieces -- Decompressor::read as the reference behaves (inflate.mbt:382-407): the
+ * caller holds a piece of the compressed stream and room for a piece of the output, never the whole of
+ * either; between two calls the decoder's state rests on the device: the 32 KiB window
+ * (dict-decoder.mbt:29-60), the Huffman tables of the block in progress (h1 / h2), the bit position
+ * inside the current byte (b / nb), a copy that did not fit (copy_len / copy_dist), final_flag
+ * (inflate.mbt:252-290).  Results, statuses and error offsets are those of flate_hip_inflate_batch on
+ * the whole stream (= the reference's), whatever the piece sizes.
+ *   in[0, in_len): the next bytes of the stream, STARTING with the bytes an earlier call reported as
+ *     unused (*in_used < in_len: move the rest to the front and append new data); final_in != 0: the
+ *     stream has no bytes behind these.  Unless final_in is set a call stops in front of a token it cannot
+ *     be sure to have whole (8 bytes; 600 bytes in front of a block header), so pieces should be a few
+ *     KiB at least; a call that cannot use anything returns FLATE_HIP_OK with *in_used = *out_len = 0.
+ *   out[0, out_cap): receives *out_len bytes.
+ *   returns FLATE_HIP_OK: call again (more input if the rest is short, more room if *out_len == out_cap);
+ *     FLATE_HIP_STREAM_END: the final block has been decoded -- reported together with the last bytes,
+ *     as Decompressor::read hands out io.EOF (:394-397); a negative code: the stream's error, sticky
+ *     (FLATE_HIP_E_CORRUPT with *err_off = corrupt_input_error's offset counted from the start of the
+ *     stream, FLATE_HIP_E_UNEXPECTED_EOF when final_in was set and the stream is not complete); the
+ *     bytes decoded in front of the error are delivered (:402-404).  in / out are HOST buffers; one
+ *     call takes at most 1 GiB each way.  One wavefront decodes one stream: the reference's semantics
+ *     for a long stream, not the engine's fast path (flate_hip_inflate_batch / _spliced are). */
+typedef struct flate_hip_inflate_stream flate_hip_inflate_stream;
+#define FLATE_HIP_STREAM_END 1
+int flate_hip_inflate_stream_open(flate_hip_ctx *ctx, flate_hip_inflate_stream **stream);
+int flate_hip_inflate_stream_read(flate_hip_inflate_stream *stream, const uint8_t *in, uint64_t in_len,
+                                  int final_in, uint8_t *out, uint64_t out_cap, uint64_t *in_used,
+                                  uint64_t *out_len, int64_t *err_off);
+void flate_hip_inflate_stream_free(flate_hip_inflate_stream *stream);
 
 /* The same for the n_streams pieces of ONE spliced stream in[0, in_len) (as written by
  * flate_hip_deflate_fast_spliced): piece i starts at bit bit_off[i] (host array, n_streams+1

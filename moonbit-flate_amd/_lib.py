@@ -18,6 +18,8 @@ EXPORTS = [
     "flate_hip_comm_plan", "flate_hip_comm_set_plan", "flate_hip_gather_layout",
     "flate_hip_gather_compressed", "flate_hip_gather_begin", "flate_hip_gather_end",
     "flate_hip_stream_open", "flate_hip_stream_bound", "flate_hip_stream_write", "flate_hip_stream_free",
+    "flate_hip_host_register", "flate_hip_host_unregister", "flate_hip_host_alloc", "flate_hip_host_free",
+    "flate_hip_inflate_stream_open", "flate_hip_inflate_stream_read", "flate_hip_inflate_stream_free",
 ]
 
 _lib = None
@@ -93,5 +95,14 @@ def load():
     L.flate_hip_stream_write.argtypes = [vp, vp, C.c_uint64, C.c_int, vp, C.c_uint64, u64p]
     L.flate_hip_stream_free.argtypes = [vp]
     L.flate_hip_stream_free.restype = None
+    L.flate_hip_inflate_stream_open.argtypes = [vp, C.POINTER(vp)]
+    L.flate_hip_inflate_stream_read.argtypes = [vp, vp, C.c_uint64, C.c_int, vp, C.c_uint64, u64p, u64p,
+                                                C.POINTER(C.c_int64)]
+    L.flate_hip_inflate_stream_free.argtypes = [vp]
+    L.flate_hip_inflate_stream_free.restype = None
+    L.flate_hip_host_register.argtypes = [vp, vp, C.c_size_t]
+    L.flate_hip_host_unregister.argtypes = [vp, vp]
+    L.flate_hip_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.flate_hip_host_free.argtypes = [vp, vp]
     _lib = L
     return L

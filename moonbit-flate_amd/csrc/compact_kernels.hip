@@ -58,4 +58,14 @@ __global__ void wait_count_kernel(const uint32_t *counter, uint32_t target, int 
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
+// The small index arrays of a call (stream offsets in, sizes and statuses out) travel by THIS kernel,
+// between the ctx's pinned staging memory and the device, not by hipMemcpyAsync: a copy command, however
+// small, queues on a DMA engine behind whatever bulk transfer another stream of the same process has
+// in flight there -- the host-pointer pipelines keep both engines busy with 100+ MiB pieces, and every
+// group's kernels then sat 5-40 ms behind them waiting for 128 KiB of offsets (flate_api.hip: ctl_up /
+// ctl_down).  A kernel reads and writes page-locked host memory directly.
+__global__ __launch_bounds__(256) void copy_ctl_kernel(uint32_t *dst, const uint32_t *src, size_t nwords) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
 }  // namespace flate

@@ -8,6 +8,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -105,6 +106,24 @@ struct flate_hip_ctx {
   uint64_t stream_rebase = 1ull << 30;  // flate_hip_stream: origin moved up past this many bytes
   int64_t debug_buffer_reset = 0;       // test hook: buffer_reset (deflate-fast.mbt:55) of streams opened from now on
   hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
+  // Host-pointer batches run their groups on TWO lanes (sub-contexts with their own streams and
+  // scratch, driven by two host threads): the persistent match-finder launch of group g+1 fills the
+  // chip while group g's last streams, its entropy kernels and its size read-back drain, which a single
+  // lane leaves idle (4 groups of 4096 streams: 19.9 ms of match finding against 16.2 for the batch
+  // as one launch).  0 = one lane (round 3's behaviour).
+  int host_lanes = 2;
+  flate_hip_ctx *lane[2] = {nullptr, nullptr};
+  // pinned staging of a call's small index arrays (ctl_up / ctl_down): they travel by a copy KERNEL,
+  // never through the DMA engines the bulk transfers of the host-pointer pipelines occupy
+  struct CtlStage {
+    uint8_t *p = nullptr;
+    size_t cap = 0, used = 0;
+  } ctl_up_buf, ctl_down_buf;
+  struct CtlPending {
+    void *host_dst;
+    size_t off, bytes;
+  };
+  std::vector<CtlPending> ctl_pending;
 };
 
 namespace flate {
@@ -139,6 +158,66 @@ void release(DevBuf &b) {
   if (b.p) (void)hipFree(b.p);
   b.p = nullptr;
   b.cap = 0;
+}
+
+// ---- small index arrays: host <-> device through pinned staging and a copy kernel (copy_ctl_kernel) ----
+// ctl_begin: room for the call's uploads / downloads (a staging buffer only grows between calls: the
+// stream is drained first).  ctl_up: stage + launch.  ctl_down: launch into the staging; the bytes reach
+// the caller's array in ctl_finish, after the stream has been synchronised.
+int ctl_begin(flate_hip_ctx *c, size_t up_bytes, size_t down_bytes) {
+  auto grow = [&](flate_hip_ctx::CtlStage &b, size_t need) -> int {
+    b.used = 0;
+    if (need <= b.cap) return FLATE_HIP_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (b.p) HIP_TRY(c, hipHostFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    const size_t want = need + (need >> 2) + 4096;
+    HIP_TRY(c, hipHostMalloc((void **)&b.p, want, hipHostMallocDefault));
+    b.cap = want;
+    return FLATE_HIP_OK;
+  };
+  c->ctl_pending.clear();
+  int rc;
+  if ((rc = grow(c->ctl_up_buf, up_bytes + 16 * 256))) return rc;
+  return grow(c->ctl_down_buf, down_bytes + 16 * 256);
+}
+
+void ctl_launch(flate_hip_ctx *c, void *dst, const void *src, size_t bytes) {
+  const size_t nwords = (bytes + 3) / 4;
+  uint32_t blocks = (uint32_t)((nwords + 255) / 256);
+  if (blocks > 512) blocks = 512;
+  if (blocks == 0) return;
+  hipLaunchKernelGGL(copy_ctl_kernel, dim3(blocks), dim3(256), 0, c->stream, (uint32_t *)dst, (const uint32_t *)src, nwords);
+}
+
+// (bytes: a multiple of 4 or rounded up to one -- every device buffer here has that slack)
+int ctl_up(flate_hip_ctx *c, void *dev_dst, const void *host_src, size_t bytes) {
+  if (!bytes) return FLATE_HIP_OK;
+  auto &b = c->ctl_up_buf;
+  const size_t at = (b.used + 255) & ~(size_t)255;
+  if (at + bytes + 4 > b.cap) return FLATE_HIP_E_INTERNAL;  // (ctl_begin was given too little)
+  memcpy(b.p + at, host_src, bytes);
+  b.used = at + bytes;
+  ctl_launch(c, dev_dst, b.p + at, bytes);
+  return FLATE_HIP_OK;
+}
+
+int ctl_down(flate_hip_ctx *c, void *host_dst, const void *dev_src, size_t bytes) {
+  if (!bytes) return FLATE_HIP_OK;
+  auto &b = c->ctl_down_buf;
+  const size_t at = (b.used + 255) & ~(size_t)255;
+  if (at + bytes + 4 > b.cap) return FLATE_HIP_E_INTERNAL;
+  b.used = at + bytes;
+  ctl_launch(c, b.p + at, dev_src, bytes);
+  c->ctl_pending.push_back({host_dst, at, bytes});
+  return FLATE_HIP_OK;
+}
+
+// after hipStreamSynchronize(c->stream)
+void ctl_finish(flate_hip_ctx *c) {
+  for (const auto &p : c->ctl_pending) memcpy(p.host_dst, c->ctl_down_buf.p + p.off, p.bytes);
+  c->ctl_pending.clear();
 }
 
 // Probe offsets of the skip heuristic (deflate-fast.mbt:178-187) from skip = 32.
@@ -238,16 +317,10 @@ int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, cons
     return rc;
   if ((rc = ensure(c, c->d_nmatch, (size_t)pl.n_chunks * 4 + 4))) return rc;
   if ((rc = ensure(c, c->d_ntok, (size_t)pl.n_chunks * 4 + 4))) return rc;
-  HIP_TRY(c, hipMemcpyAsync(c->d_in_off.p, in_off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice,
-                            c->stream));
-  HIP_TRY(c, hipMemcpyAsync(c->d_chunk_base.p, pl.chunk_base.data(), ((size_t)n + 1) * 4,
-                            hipMemcpyHostToDevice, c->stream));
-  if (!pl.ids16.empty())
-    HIP_TRY(c, hipMemcpyAsync(c->d_ids16.p, pl.ids16.data(), pl.ids16.size() * 4,
-                              hipMemcpyHostToDevice, c->stream));
-  if (!pl.ids32.empty())
-    HIP_TRY(c, hipMemcpyAsync(c->d_ids32.p, pl.ids32.data(), pl.ids32.size() * 4,
-                              hipMemcpyHostToDevice, c->stream));
+  if ((rc = ctl_up(c, c->d_in_off.p, in_off, ((size_t)n + 1) * 8))) return rc;
+  if ((rc = ctl_up(c, c->d_chunk_base.p, pl.chunk_base.data(), ((size_t)n + 1) * 4))) return rc;
+  if ((rc = ctl_up(c, c->d_ids16.p, pl.ids16.data(), pl.ids16.size() * 4))) return rc;
+  if ((rc = ctl_up(c, c->d_ids32.p, pl.ids32.data(), pl.ids32.size() * 4))) return rc;
 
   LzParams P{};  // (value-initialised: a field added later must never reach a kernel as stack garbage)
   P.in = d_in;
@@ -501,6 +574,12 @@ void flate_hip_destroy(flate_hip_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+  for (auto &l : c->lane) {
+    flate_hip_destroy(l);
+    l = nullptr;
+  }
+  if (c->ctl_up_buf.p) (void)hipHostFree(c->ctl_up_buf.p);
+  if (c->ctl_down_buf.p) (void)hipHostFree(c->ctl_down_buf.p);
   if (c->h2d_stream) (void)hipStreamDestroy(c->h2d_stream);
   if (c->d2h_stream) (void)hipStreamDestroy(c->d2h_stream);
   for (DevBuf *b : {&c->scan_tab, &c->d_in, &c->d_out, &c->d_in_off, &c->d_chunk_base, &c->d_ids16,
@@ -554,6 +633,8 @@ int flate_hip_set_option(flate_hip_ctx *c, const char *name, int64_t value) {
     c->host_groups = (int)value;
   } else if (k == "host_pipeline_group_streams" && value > 0 && value <= 0x7fffffff) {
     c->host_group_streams = (uint32_t)value;
+  } else if (k == "host_pipeline_lanes" && value >= 1 && value <= 2) {
+    c->host_lanes = (int)value;
   } else if (k == "profile_split_streams" && value >= 0 && value <= 0x7fffffff) {
     c->profile_split = (uint32_t)value;
   } else if (k == "window_units" && (value == 0 || value == 1)) {
@@ -576,6 +657,44 @@ int flate_hip_set_option(flate_hip_ctx *c, const char *name, int64_t value) {
   } else {
     return FLATE_HIP_E_INVALID;
   }
+  return FLATE_HIP_OK;
+}
+
+// Host buffers the caller keeps across calls (a Writer's input buffer, a Reader's output buffer): once
+// page-locked, the copies of the host-pointer calls are DMA transfers at the link's rate; from pageable
+// memory the runtime stages every copy through bounce buffers of its own.  Nothing else changes: the
+// copy paths hand the same pointers to hipMemcpyAsync, which knows the registered ranges.
+int flate_hip_host_register(flate_hip_ctx *c, void *p, size_t bytes) {
+  if (!c || !p || !bytes) return FLATE_HIP_E_INVALID;
+  c->hip_err.clear();
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipHostRegister(p, bytes, hipHostRegisterDefault));
+  return FLATE_HIP_OK;
+}
+
+int flate_hip_host_unregister(flate_hip_ctx *c, void *p) {
+  if (!c || !p) return FLATE_HIP_E_INVALID;
+  c->hip_err.clear();
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipHostUnregister(p));
+  return FLATE_HIP_OK;
+}
+
+int flate_hip_host_alloc(flate_hip_ctx *c, size_t bytes, void **out) {
+  if (!c || !out || !bytes) return FLATE_HIP_E_INVALID;
+  *out = nullptr;
+  c->hip_err.clear();
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return FLATE_HIP_OK;
+}
+
+int flate_hip_host_free(flate_hip_ctx *c, void *p) {
+  if (!c) return FLATE_HIP_E_INVALID;
+  if (!p) return FLATE_HIP_OK;
+  c->hip_err.clear();
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipHostFree(p));
   return FLATE_HIP_OK;
 }
 
@@ -622,6 +741,10 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
   if (rc) return rc;
   const bool dev = (flags & FLATE_HIP_DEVICE_PTRS) != 0;
   const uint64_t in_bytes = in_off[n];
+  // the call's index arrays: in_off, chunk_base, blk_base (n + 1 each), the two stream lists, blk_sid
+  if ((rc = ctl_begin(c, ((size_t)n + 1) * 16 + (pl.ids16.size() + pl.ids32.size() + (size_t)pl.n_blocks) * 4,
+                      ((size_t)n + 1) * 8 + 64)))
+    return rc;
 
   const uint8_t *d_in = in;
   uint8_t *d_out = out;
@@ -644,8 +767,7 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
   if (spliced) {
     if ((rc = ensure(c, c->d_slot_off, ((size_t)n + 1) * 16))) return rc;  // stream summaries {a, b}
   }
-  HIP_TRY(c, hipMemcpyAsync(c->d_blk_base.p, pl.blk_base.data(), ((size_t)n + 1) * 4,
-                            hipMemcpyHostToDevice, c->stream));
+  if ((rc = ctl_up(c, c->d_blk_base.p, pl.blk_base.data(), ((size_t)n + 1) * 4))) return rc;
   HIP_TRY(c, hipMemsetAsync(c->d_status.p, 0, 4, c->stream));
   // One wavefront per block in the histogram and pack kernels when the streams have many blocks
   // (4096 streams of four windows are 4096 wavefronts per stream-kernel, a quarter of what fills
@@ -662,8 +784,7 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
     for (uint32_t i = 0; i < n; ++i)
       for (uint32_t b = pl.blk_base[i]; b < pl.blk_base[i + 1]; ++b) blk_sid[b] = i;
     if ((rc = ensure(c, c->d_blk_sid, (size_t)pl.n_blocks * 4 + 4))) return rc;
-    HIP_TRY(c, hipMemcpyAsync(c->d_blk_sid.p, blk_sid.data(), (size_t)pl.n_blocks * 4, hipMemcpyHostToDevice,
-                              c->stream));
+    if ((rc = ctl_up(c, c->d_blk_sid.p, blk_sid.data(), (size_t)pl.n_blocks * 4))) return rc;
   }
 
   // Overlap (see flate_hip_ctx::overlap_sub): possible when the match finder is ONE persistent
@@ -785,14 +906,12 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
   HIP_TRY(c, hipGetLastError());
 
   uint64_t produced = 0;
-  if (out_off)
-    HIP_TRY(c, hipMemcpyAsync(out_off, c->d_out_off.p, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost,
-                              c->stream));
-  if (spliced)
-    HIP_TRY(c, hipMemcpyAsync(&c->h_total_bytes, (uint64_t *)c->d_out_len.p + n, 8, hipMemcpyDeviceToHost,
-                              c->stream));
-  HIP_TRY(c, hipMemcpyAsync(&c->h_status_word, c->d_status.p, 4, hipMemcpyDeviceToHost, c->stream));
+  if (out_off && (rc = ctl_down(c, out_off, c->d_out_off.p, ((size_t)n + 1) * 8))) return rc;
+  if (spliced && (rc = ctl_down(c, &c->h_total_bytes, (uint64_t *)c->d_out_len.p + n, 8))) return rc;
+  if ((rc = ctl_down(c, &c->h_status_word, c->d_status.p, 4))) return rc;
+  HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  ctl_finish(c);
   if (c->h_status_word) {
     if (c->h_status_word == kStatusLanesLost) {
       c->hip_err = "a persistent match-finder loop lost lanes of its wavefront (miscompiled loop?)";
@@ -841,6 +960,18 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
   return collect_timing(c, used);
 }
 
+// FLATE_HIP_TRACE_HOST=1: timestamps of the host-pointer pipeline's stages on stderr (developer aid)
+static bool host_trace_on() {
+  static const bool on = getenv("FLATE_HIP_TRACE_HOST") != nullptr;
+  return on;
+}
+static double host_now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static void host_trace(double t0, const char *what, unsigned g, double a, double b) {
+  if (host_trace_on()) fprintf(stderr, "[host-pipe] %-8s g=%u  %.2f .. %.2f ms\n", what, g, a - t0, b - t0);
+}
+
 // ---- host-pointer batches, pipelined over groups of streams (flate_hip_ctx::host_groups) ----
 // Two copy threads beside the calling thread: one brings the groups' input to the device in
 // order, the other takes every group's output back as soon as the caller posts it.  Each uses its
@@ -865,7 +996,9 @@ class CopyPipe {
           std::lock_guard<std::mutex> l(mu_);
           if (stop_) return;
         }
+        const double a = host_now_ms();
         const bool ok = run(in_jobs[g], hipMemcpyHostToDevice, s_in, "host-to-device copy: ");
+        host_trace(t0_, "h2d", (unsigned)g, a, host_now_ms());
         std::lock_guard<std::mutex> l(mu_);
         in_ready_[g] = ok ? 1 : -1;
         cv_.notify_all();
@@ -882,7 +1015,9 @@ class CopyPipe {
           if (out_state_[g] < 0) return;
           j = out_jobs_[g];
         }
+        const double a = host_now_ms();
         if (!run(j, hipMemcpyDeviceToHost, s_out, "device-to-host copy: ")) return;
+        host_trace(t0_, "d2h", (unsigned)g, a, host_now_ms());
       }
     });
   }
@@ -923,6 +1058,7 @@ class CopyPipe {
     if (err_.empty()) err_ = std::string(what) + hipGetErrorString(e);
     return false;
   }
+  double t0_ = host_now_ms();
   std::mutex mu_;
   std::condition_variable cv_;
   std::vector<int> in_ready_, out_state_;  // 0 pending, 1 done / posted, -1 failed / dropped
@@ -955,49 +1091,146 @@ int host_pipe_streams(flate_hip_ctx *c) {
 }
 }  // namespace
 
+// The launch options of the parent, as they are now, for a lane's sub-context.
+static void lane_options(flate_hip_ctx *dst, const flate_hip_ctx *src) {
+  dst->guest_blocks = src->guest_blocks;
+  dst->guest_min = src->guest_min;
+  dst->resident_blocks = src->resident_blocks;
+  dst->window_units = src->window_units;
+  dst->entropy_per_block = src->entropy_per_block;
+  dst->overlap_sub = src->overlap_sub;
+  dst->overlap_resident = src->overlap_resident;
+  dst->spin_limit = src->spin_limit;
+  dst->profile_split = src->profile_split;
+  dst->profiling = src->profiling;
+  dst->host_groups = 0;
+}
+
 // The streams are independent, so the bytes are those of one call over the whole batch.
+// Group g is compressed on lane g % lanes into its own slot of the device output (the slots are
+// sized by the groups' bounds: where a group's bytes end up in `out` depends on the sizes of the
+// groups before it, which the host only learns as they finish); the calling thread takes the groups
+// in order, fills the index and posts each group's bytes to the copy-out thread.
 static int deflate_host_pipelined(flate_hip_ctx *c, const uint8_t *in, const uint64_t *in_off, uint32_t n,
                                   uint8_t *out, uint64_t out_cap, uint64_t *out_off, uint32_t flags,
                                   uint32_t G) {
   HIP_TRY(c, hipSetDevice(c->device));
   int rc;
-  if ((rc = ensure(c, c->d_in, in_off[n] + 16))) return rc;
-  if ((rc = ensure(c, c->d_out, out_cap + 16))) return rc;
-  if ((rc = host_pipe_streams(c))) return rc;
-  uint8_t *d_in = (uint8_t *)c->d_in.p, *d_out = (uint8_t *)c->d_out.p;
+  const int lanes = c->host_lanes > 1 ? 2 : 1;
+  for (int k = 0; k < lanes; ++k) {
+    if (!c->lane[k] && (rc = flate_hip_init(c->device, &c->lane[k]))) return rc;
+    lane_options(c->lane[k], c);
+  }
   std::vector<uint32_t> lo(G + 1);
   std::vector<CopyJob> in_jobs(G);
   cut_by_bytes(in_off, nullptr, n, G, lo);  // equal BYTES per group: copy and compute stages stay balanced
+  // device slots of the groups' output
+  std::vector<uint64_t> slot(G + 1, 0);
+  for (uint32_t g = 0; g < G; ++g) {
+    uint64_t bound = 0;
+    for (uint32_t i = lo[g]; i < lo[g + 1]; ++i) bound += flate_hip_deflate_bound((size_t)(in_off[i + 1] - in_off[i]));
+    if (bound > out_cap) bound = out_cap;  // (a group that needs more than that fails the call anyway)
+    slot[g + 1] = slot[g] + ((bound + 255) & ~255ull);
+  }
+  if ((rc = ensure(c, c->d_in, in_off[n] + 16))) return rc;
+  if ((rc = ensure(c, c->d_out, slot[G] + 16))) return rc;
+  if ((rc = host_pipe_streams(c))) return rc;
+  uint8_t *d_in = (uint8_t *)c->d_in.p, *d_out = (uint8_t *)c->d_out.p;
   for (uint32_t g = 0; g < G; ++g)
     in_jobs[g] = {d_in + in_off[lo[g]], in + in_off[lo[g]], (size_t)(in_off[lo[g + 1]] - in_off[lo[g]])};
+  const double t_call = host_now_ms();
   CopyPipe pipe(G, G);
   pipe.start(c->device, c->h2d_stream, c->d2h_stream, in_jobs);
 
+  struct GroupResult {
+    std::vector<uint64_t> off;
+    int rc = FLATE_HIP_OK;
+    bool done = false;
+    float stage[FLATE_HIP_STAGE_COUNT] = {0, 0, 0, 0};
+    std::string err;
+  };
+  std::vector<GroupResult> res(G);
+  std::mutex mu;
+  std::condition_variable cv;
+  bool stop = false;
+  auto run_lane = [&](int k) {
+    flate_hip_ctx *lc = c->lane[k];
+    std::vector<uint64_t> gin;
+    for (uint32_t g = (uint32_t)k; g < G; g += (uint32_t)lanes) {
+      GroupResult &r = res[g];
+      {
+        std::lock_guard<std::mutex> l(mu);
+        if (stop) r.rc = FLATE_HIP_E_INTERNAL;
+      }
+      if (r.rc == FLATE_HIP_OK && !pipe.wait_in(g)) r.rc = FLATE_HIP_E_HIP;
+      const uint32_t cnt = lo[g + 1] - lo[g];
+      r.off.assign((size_t)cnt + 1, 0);
+      if (r.rc == FLATE_HIP_OK && cnt) {
+        gin.resize((size_t)cnt + 1);
+        const uint64_t base = in_off[lo[g]];
+        for (uint32_t i = 0; i <= cnt; ++i) gin[i] = in_off[lo[g] + i] - base;
+        lc->hip_err.clear();
+        const double a = host_now_ms();
+        r.rc = deflate_common(lc, d_in + base, gin.data(), cnt, d_out + slot[g], slot[g + 1] - slot[g], r.off.data(),
+                              flags | FLATE_HIP_DEVICE_PTRS, false, nullptr);
+        host_trace(t_call, "compute", g, a, host_now_ms());
+        for (int s = 0; s < FLATE_HIP_STAGE_COUNT; ++s) r.stage[s] = lc->stage_ms[s];
+        if (r.rc != FLATE_HIP_OK) r.err = lc->hip_err;
+      }
+      std::lock_guard<std::mutex> l(mu);
+      r.done = true;
+      if (r.rc != FLATE_HIP_OK) stop = true;
+      cv.notify_all();
+    }
+  };
+  // (the calling thread only collects; a thread that cannot be started ends the others before the
+  // exception travels on to the caller, which then runs the batch as one pass)
+  std::thread workers[2];
+  try {
+    for (int k = 0; k < lanes; ++k) workers[k] = std::thread(run_lane, k);
+  } catch (...) {
+    {
+      std::lock_guard<std::mutex> l(mu);
+      stop = true;
+    }
+    (void)pipe.finish();
+    for (auto &w : workers)
+      if (w.joinable()) w.join();
+    throw;
+  }
+
   float stage_sum[FLATE_HIP_STAGE_COUNT] = {0, 0, 0, 0};
-  std::vector<uint64_t> goff, gin;
   uint64_t at = 0;
   rc = FLATE_HIP_OK;
   out_off[0] = 0;
-  for (uint32_t g = 0; g < G; ++g) {
-    if (!pipe.wait_in(g)) {
-      rc = FLATE_HIP_E_HIP;
+  for (uint32_t g = 0; g < G && rc == FLATE_HIP_OK; ++g) {
+    GroupResult &r = res[g];
+    {
+      std::unique_lock<std::mutex> l(mu);
+      cv.wait(l, [&] { return r.done; });
+    }
+    if (r.rc != FLATE_HIP_OK) {
+      rc = r.rc;
+      if (c->hip_err.empty()) c->hip_err = r.err;
       break;
     }
     const uint32_t cnt = lo[g + 1] - lo[g];
-    gin.resize((size_t)cnt + 1);
-    goff.assign((size_t)cnt + 1, 0);
-    const uint64_t base = in_off[lo[g]];
-    for (uint32_t i = 0; i <= cnt; ++i) gin[i] = in_off[lo[g] + i] - base;
-    if (cnt) {
-      rc = deflate_common(c, d_in + base, gin.data(), cnt, d_out + at, out_cap - at, goff.data(),
-                          flags | FLATE_HIP_DEVICE_PTRS, false, nullptr);
-      if (rc != FLATE_HIP_OK) break;
-      for (int k = 0; k < FLATE_HIP_STAGE_COUNT; ++k) stage_sum[k] += c->stage_ms[k];
+    const uint64_t bytes = r.off[cnt];
+    if (at + bytes > out_cap) {
+      rc = FLATE_HIP_E_OUT_TOO_SMALL;
+      break;
     }
-    for (uint32_t i = 1; i <= cnt; ++i) out_off[lo[g] + i] = at + goff[i];
-    pipe.post_out(g, {out + at, d_out + at, (size_t)goff[cnt]});
-    at += goff[cnt];
+    for (uint32_t i = 1; i <= cnt; ++i) out_off[lo[g] + i] = at + r.off[i];
+    pipe.post_out(g, {out + at, d_out + slot[g], (size_t)bytes});
+    at += bytes;
+    for (int k = 0; k < FLATE_HIP_STAGE_COUNT; ++k) stage_sum[k] += r.stage[k];
   }
+  {
+    std::lock_guard<std::mutex> l(mu);
+    if (rc != FLATE_HIP_OK) stop = true;
+  }
+  for (auto &w : workers)
+    if (w.joinable()) w.join();
   const std::string err = pipe.finish();
   if (rc == FLATE_HIP_OK && !err.empty()) rc = FLATE_HIP_E_HIP;
   if (rc == FLATE_HIP_E_HIP && c->hip_err.empty()) c->hip_err = err;
@@ -1281,6 +1514,99 @@ int flate_hip_stream_write(flate_hip_stream *st, const uint8_t *in, uint64_t n, 
   return rc;
 }
 
+}  // extern "C"
+
+// ---- one long stream decoded in pieces (Decompressor::read as the reference behaves: the caller
+// ---- holds a piece of input and a piece of output, never the whole stream; inflate.mbt:382-407) ----
+struct flate_hip_inflate_stream {
+  flate_hip_ctx *ctx = nullptr;
+  DevBuf state, in, out;
+  int status = 0;           // sticky: 1 = the final block is done, < 0 = error
+  int64_t err_off = -1;
+  uint32_t bit_in_byte = 0; // of the byte the next call's input starts with
+  uint64_t total_in = 0, total_out = 0;
+};
+
+extern "C" {
+
+int flate_hip_inflate_stream_open(flate_hip_ctx *c, flate_hip_inflate_stream **out) {
+  if (!c || !out) return FLATE_HIP_E_INVALID;
+  *out = nullptr;
+  c->hip_err.clear();
+  HIP_TRY(c, hipSetDevice(c->device));
+  flate_hip_inflate_stream *st = new flate_hip_inflate_stream();
+  st->ctx = c;
+  int rc = ensure(c, st->state, inflate_stream_state_bytes() + 64);
+  if (rc == FLATE_HIP_OK) {
+    hipLaunchKernelGGL(inflate_stream_init_kernel, dim3(1), dim3(64), 0, c->stream, st->state.p);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) rc = FLATE_HIP_E_HIP;
+  }
+  if (rc != FLATE_HIP_OK) {
+    release(st->state);
+    delete st;
+    return rc;
+  }
+  *out = st;
+  return FLATE_HIP_OK;
+}
+
+void flate_hip_inflate_stream_free(flate_hip_inflate_stream *st) {
+  if (!st) return;
+  (void)hipSetDevice(st->ctx->device);
+  for (DevBuf *b : {&st->state, &st->in, &st->out}) release(*b);
+  delete st;
+}
+
+int flate_hip_inflate_stream_read(flate_hip_inflate_stream *st, const uint8_t *in, uint64_t in_len, int final_in,
+                                  uint8_t *out, uint64_t out_cap, uint64_t *in_used, uint64_t *out_len,
+                                  int64_t *err_off) {
+  if (!st || !in_used || !out_len || (in_len && !in) || (out_cap && !out)) return FLATE_HIP_E_INVALID;
+  *in_used = *out_len = 0;
+  if (err_off) *err_off = st->err_off;
+  if (st->status) return st->status == 1 ? FLATE_HIP_STREAM_END : st->status;  // sticky (Decompressor.err, inflate.mbt:285,398)
+  // the byte that holds the next unconsumed bit was reported as unused: it has to be here again
+  if (st->bit_in_byte && in_len == 0) return final_in ? FLATE_HIP_E_UNEXPECTED_EOF : FLATE_HIP_OK;
+  if (in_len == 0 && !final_in) return FLATE_HIP_OK;  // nothing to decode from
+  flate_hip_ctx *c = st->ctx;
+  c->hip_err.clear();
+  HIP_TRY(c, hipSetDevice(c->device));
+  // one call takes at most 1 GiB each way (32-bit positions inside the kernel); more input than that is
+  // simply not all used, and not final
+  const uint64_t kPiece = 1ull << 30;
+  if (in_len > kPiece) {
+    in_len = kPiece;
+    final_in = 0;
+  }
+  if (out_cap > kPiece) out_cap = kPiece;
+  int rc;
+  if ((rc = ensure(c, st->in, in_len + 16))) return rc;
+  if ((rc = ensure(c, st->out, out_cap + 16))) return rc;
+  if (in_len) HIP_TRY(c, hipMemcpyAsync(st->in.p, in, in_len, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(inflate_stream_kernel, dim3(1), dim3(64), 0, c->stream, st->state.p, (const uint8_t *)st->in.p,
+                     (uint32_t)in_len, final_in ? 1u : 0u, (uint8_t *)st->out.p, (uint32_t)out_cap);
+  HIP_TRY(c, hipGetLastError());
+  InfStreamResult r{};
+  HIP_TRY(c, hipMemcpyAsync(&r, st->state.p, sizeof r, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (r.out_len > out_cap || r.in_used > in_len) return FLATE_HIP_E_INTERNAL;
+  if (r.out_len) {
+    HIP_TRY(c, hipMemcpyAsync(out, st->out.p, r.out_len, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  *in_used = r.in_used;
+  *out_len = r.out_len;
+  st->bit_in_byte = r.bit_in_byte;
+  st->total_in = r.total_in;
+  st->total_out = r.total_out;
+  if (r.status) {
+    st->status = r.status;
+    st->err_off = r.err_off;
+    if (err_off) *err_off = r.err_off;
+    return r.status == 1 ? FLATE_HIP_STREAM_END : r.status;
+  }
+  return FLATE_HIP_OK;
+}
+
 int flate_hip_lz77_matches(flate_hip_ctx *c, const uint8_t *in, const uint64_t *in_off, uint32_t n,
                            uint32_t flags, uint32_t *n_chunks, uint64_t *n_recs_cap,
                            uint32_t *chunk_nmatch, uint64_t *chunk_rec_off, uint32_t *recs) {
@@ -1303,6 +1629,7 @@ int flate_hip_lz77_matches(flate_hip_ctx *c, const uint8_t *in, const uint64_t *
     d_in = (const uint8_t *)c->d_in.p;
   }
   HIP_TRY(c, hipMemsetAsync(c->d_status.p, 0, 4, c->stream));
+  if ((rc = ctl_begin(c, ((size_t)n + 1) * 12 + (pl.ids16.size() + pl.ids32.size()) * 4, 64))) return rc;
   if ((rc = run_lz77(c, d_in, in_off, pl, flags))) return rc;
   HIP_TRY(c, hipMemcpyAsync(chunk_nmatch, c->d_nmatch.p, (size_t)pl.n_chunks * 4,
                             hipMemcpyDeviceToHost, c->stream));
@@ -1359,8 +1686,9 @@ static int inflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
   if ((rc = ensure(c, c->d_out_len, (size_t)n * 8 + 8))) return rc;
   if ((rc = ensure(c, c->d_istatus, (size_t)n * 4 + 4))) return rc;
   if ((rc = ensure(c, c->d_ierr, (size_t)n * 8 + 8))) return rc;
-  HIP_TRY(c, hipMemcpyAsync(c->d_in_off.p, in_off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(c->d_slot_off.p, out_off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  if ((rc = ctl_begin(c, ((size_t)n + 1) * 16, (size_t)n * 20 + 64))) return rc;
+  if ((rc = ctl_up(c, c->d_in_off.p, in_off, ((size_t)n + 1) * 8))) return rc;
+  if ((rc = ctl_up(c, c->d_slot_off.p, out_off, ((size_t)n + 1) * 8))) return rc;
   InfParams I{};
   I.in = d_in;
   I.in_off = (const uint64_t *)c->d_in_off.p;
@@ -1409,12 +1737,14 @@ static int inflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
       hipLaunchKernelGGL(inflate_kernel, dim3(n), dim3(64), 0, c->stream, I);
   }
   HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, hipMemcpyAsync(out_len, c->d_out_len.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(status, c->d_istatus.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(err_off, c->d_ierr.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+  if ((rc = ctl_down(c, out_len, c->d_out_len.p, (size_t)n * 8))) return rc;
+  if ((rc = ctl_down(c, status, c->d_istatus.p, (size_t)n * 4))) return rc;
+  if ((rc = ctl_down(c, err_off, c->d_ierr.p, (size_t)n * 8))) return rc;
   if (!dev && !size_only)
     HIP_TRY(c, hipMemcpyAsync(out, c->d_out.p, out_off[n], hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  ctl_finish(c);
   const bool used[FLATE_HIP_STAGE_COUNT] = {false, false, false, true};
   if ((rc = collect_timing(c, used))) return rc;
   for (uint32_t i = 0; i < n; ++i)
@@ -1438,6 +1768,7 @@ static int inflate_host_pipelined(flate_hip_ctx *c, const uint8_t *in, const uin
   cut_by_bytes(in_off, out_off, n, G, lo);  // by input + output bytes (both cross PCIe)
   for (uint32_t g = 0; g < G; ++g)
     in_jobs[g] = {d_in + in_off[lo[g]], in + in_off[lo[g]], (size_t)(in_off[lo[g + 1]] - in_off[lo[g]])};
+  const double t_call = host_now_ms();
   CopyPipe pipe(G, G);
   pipe.start(c->device, c->h2d_stream, c->d2h_stream, in_jobs);
   float stage_sum[FLATE_HIP_STAGE_COUNT] = {0, 0, 0, 0};
@@ -1457,8 +1788,10 @@ static int inflate_host_pipelined(flate_hip_ctx *c, const uint8_t *in, const uin
       gout[i] = out_off[a + i] - out_off[a];
     }
     if (cnt) {
+      const double ta = host_now_ms();
       const int r = inflate_common(c, d_in + in_off[a], gin.data(), cnt, d_out + out_off[a], gout.data(),
                                    out_len + a, status + a, err_off + a, flags | FLATE_HIP_DEVICE_PTRS, 0);
+      host_trace(t_call, "compute", g, ta, host_now_ms());
       // a stream's own failure (its status, also the return value) does not stop the batch: as in
       // one pass, every stream is decoded and the first failing status is what the call returns
       const bool stream_status = r == FLATE_HIP_E_CORRUPT || r == FLATE_HIP_E_UNEXPECTED_EOF ||

@@ -148,6 +148,8 @@ __global__ void huff_zero_edges_kernel(HuffParams P, uint32_t n_blocks);
 __global__ void huff_pack_block_kernel(HuffParams P);
 __global__ void uq_init_kernel(uint32_t *ready, uint32_t *ctr, uint32_t n_streams, uint32_t n_units);
 __global__ void scan_sizes_kernel(CompactParams P);
+// small index arrays between pinned host staging and the device (see compact_kernels.hip)
+__global__ void copy_ctl_kernel(uint32_t *dst, const uint32_t *src, size_t nwords);
 // spins (bounded) until *counter >= target: gates a sub-batch of the entropy stage on the match
 // finder that is still running on another stream
 __global__ void wait_count_kernel(const uint32_t *counter, uint32_t target, int *status, uint32_t spin_limit);
@@ -164,6 +166,19 @@ __global__ void inflate_spec_kernel(InfParams P);
 #endif
 template <int LPW>
 __global__ void inflate_simt_kernel(InfParams P);
+// one long stream decoded in pieces (inflate_stream_kernel.inc): the decoder's state -- the 32 KiB
+// window, the tables of the block in progress, the bit carry, a copy that did not fit -- rests in
+// `state` (inflate_stream_state_bytes()) between launches; its first 64 bytes are InfStreamResult
+struct InfStreamResult {
+  uint64_t total_in, total_out;
+  int64_t err_off;
+  int32_t status;  // 0 = call again, 1 = the final block is done, < 0 = error (sticky)
+  uint32_t in_used, out_len, bit_in_byte;
+};
+size_t inflate_stream_state_bytes();
+__global__ void inflate_stream_init_kernel(void *state);
+__global__ void inflate_stream_kernel(void *state, const uint8_t *in, uint32_t in_len, uint32_t final_in,
+                                      uint8_t *out, uint32_t out_cap);
 
 // splice (splice_kernels.hip): bit positions of the streams inside one spliced DEFLATE stream
 struct SpliceParams {

@@ -539,6 +539,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(InfParams P) {
   }
 }
 
+#include "inflate_stream_kernel.inc"
 #include "inflate_spec_kernel.inc"
 template __global__ void inflate_spec_kernel<FLATE_SPEC_SMALL>(InfParams);
 template __global__ void inflate_spec_kernel<FLATE_SPEC_LARGE>(InfParams);

@@ -112,6 +112,32 @@ class FlateEngine:
         """Launch on the given hipStream_t (int address), e.g. torch.cuda.current_stream().cuda_stream."""
         self._check(self._L.flate_hip_set_stream(self._ctx, C.c_void_p(hip_stream_ptr or None)))
 
+    def host_register(self, arr):
+        """Page-lock a host buffer the caller keeps across calls (flate_hip_host_register): the copies of
+        the host-pointer calls then run at the link's rate.  Returns a context manager that
+        unregisters on exit (or call .close())."""
+        a = np.ascontiguousarray(arr)
+        assert a is arr or np.shares_memory(a, arr), "host_register needs a contiguous array"
+        self._check(self._L.flate_hip_host_register(self._ctx, a.ctypes.data, a.nbytes))
+        eng = self
+
+        class _Reg:
+            def __init__(self):
+                self.ptr = a.ctypes.data
+
+            def close(self):
+                if self.ptr:
+                    eng._check(eng._L.flate_hip_host_unregister(eng._ctx, self.ptr))
+                    self.ptr = None
+
+            def __enter__(self):
+                return self
+
+            def __exit__(self, *exc):
+                self.close()
+
+        return _Reg()
+
     def set_option(self, name, value):
         """Launch-geometry knobs (guest_blocks, resident_blocks, guest_min_streams)."""
         self._check(self._L.flate_hip_set_option(self._ctx, name.encode(), int(value)))
@@ -224,6 +250,10 @@ class FlateEngine:
         if rc != 0 and rc not in (E_OUT_TOO_SMALL, E_CORRUPT, E_UNEXPECTED_EOF):
             self._check(rc)
         return out_len[:n], status[:n], err_off[:n]
+
+    def open_inflate_stream(self):
+        """One long DEFLATE stream decoded in pieces (see StreamReader)."""
+        return StreamReader(self)
 
     def open_stream(self, compat_go=False):
         """One stream written in pieces (flate_hip_stream_*): see StreamWriter."""
@@ -356,6 +386,52 @@ class StreamWriter:
     def free(self):
         if self._st:
             self._L.flate_hip_stream_free(self._st)
+            self._st = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class StreamReader:
+    """Decompressor::read as the reference behaves for ONE long stream (flate_hip_inflate_stream_*): the
+    caller feeds pieces of the compressed stream and takes pieces of output; the decoder's state rests
+    on the device in between.  `feed(piece, final, room)` returns (out bytes, status): status 0 = go on,
+    1 = end of stream, < 0 = the stream's error (err_off holds corrupt_input_error's offset)."""
+
+    def __init__(self, eng):
+        self._eng, self._L = eng, eng._L
+        self._st = C.c_void_p()
+        eng._check(self._L.flate_hip_inflate_stream_open(eng._ctx, C.byref(self._st)))
+        self._rest = np.zeros(0, dtype=np.uint8)  # bytes a call reported as unused
+        self.err_off = -1
+        self.total_in = 0
+
+    def feed(self, piece, final=False, room=1 << 20):
+        piece = np.ascontiguousarray(np.frombuffer(bytes(piece), dtype=np.uint8) if not isinstance(piece, np.ndarray) else piece,
+                                     dtype=np.uint8)
+        buf = np.concatenate([self._rest, piece]) if self._rest.size else piece
+        out = np.empty(max(int(room), 1), dtype=np.uint8)
+        used, n, eo = C.c_uint64(0), C.c_uint64(0), C.c_int64(-1)
+        rc = self._L.flate_hip_inflate_stream_read(self._st, buf.ctypes.data if buf.size else None, buf.size,
+                                                   1 if final else 0, out.ctypes.data, int(room), C.byref(used),
+                                                   C.byref(n), C.byref(eo))
+        if rc not in (0, 1, E_CORRUPT, E_UNEXPECTED_EOF):
+            self._eng._check(rc)
+        self._rest = buf[int(used.value):].copy()
+        self.total_in += int(used.value)
+        self.err_off = int(eo.value)
+        return out[:int(n.value)], rc
+
+    @property
+    def pending_input(self):
+        return int(self._rest.size)
+
+    def free(self):
+        if self._st:
+            self._L.flate_hip_inflate_stream_free(self._st)
             self._st = C.c_void_p()
 
     def __del__(self):
