@@ -83,15 +83,20 @@ int flate_hip_set_stream(flate_hip_ctx *ctx, void *hip_stream);
  *                        between its windows); 0: one block keeps a stream from start to end
  *   "host_pipeline_groups"  host-pointer calls of flate_hip_deflate_fast_batch / flate_hip_inflate_batch
  *                        on >= 64 MiB: the batch is cut into this many groups of streams (each at
- *                        least 4096 streams, for inflate 16384) and
+ *                        least 2048 streams, for inflate 8192) and
  *                        group g is compressed while group g+1 is copied in and the output of g-1
- *                        is copied out (default 4; 0 or 1: copy in, compress, copy out).  The
+ *                        is copied out (default 8; 0 or 1: copy in, compress, copy out).  The
  *                        groups hold equal BYTES (not equal stream counts).  Such a call starts
- *                        two copy threads of its own for its duration.  If it fails part-way
+ *                        two copy threads (and, for the encoder, "host_pipeline_lanes" compute
+ *                        threads) of its own for its duration.  If it fails part-way
  *                        (FLATE_HIP_E_OUT_TOO_SMALL, a HIP error) out and out_off are partly
  *                        written and must not be used; inflate: a failing stream does not stop
  *                        the batch, every stream's status is reported as in one pass
- *   "host_pipeline_group_streams"  smallest group of such a call (default 4096 streams)
+ *   "host_pipeline_group_streams"  smallest group of such a call (default 2048 streams)
+ *   "host_pipeline_lanes"  2 (default): the groups of a host-pointer encode call alternate between two
+ *                        lanes (sub-contexts with their own HIP streams and scratch, one host thread
+ *                        each), so that the match finder of group g+1 fills the chip while group g's
+ *                        last streams, entropy kernels and size read-back drain; 1: one lane
  *   "overlap_sub_batches"  > 0: the entropy kernels of every sub-batch (queue order) run on a
  *                        second HIP stream as soon as the match finder has counted its streams
  *                        done (default 0: measured slower on MI355X)

@@ -1,9 +1,10 @@
 /*
  * flate_hip_stub.c -- the few lines of C the MoonBit native backend needs next to
  * libflate_hip.so.  MoonBit's `extern "C"` cannot take
- * a pointer-to-pointer and has no null test for an #external type, so the three constructors
- * (ctx, comm, stream) and their null tests are wrapped, and the size-only inflate pass fixes its NULL
- * arguments; everything else binds include/flate_hip.h directly.  UNVERIFIED with moon (not available in the build image); this file
+ * a pointer-to-pointer and has no null test for an #external type, so the four constructors
+ * (ctx, comm, stream, inflate stream) and their null tests are wrapped, the size-only inflate pass fixes its
+ * NULL arguments and the piecewise read packs its three results into one array; everything else binds
+ * include/flate_hip.h directly.  UNVERIFIED with moon (not available in the build image); this file
  * itself is compiled by tests/test_library_abi.py to keep it in step with the header.
  */
 #include "flate_hip.h"
@@ -44,4 +45,23 @@ int flate_hip_mbt_stream_is_null(const flate_hip_stream *st) { return st == 0; }
 int flate_hip_mbt_inflate_sizes(flate_hip_ctx *c, const uint8_t *in, const uint64_t *in_off, uint32_t n,
                                 uint64_t *out_len, int32_t *status, int64_t *err_off) {
   return flate_hip_inflate_batch(c, in, in_off, n, 0, 0, out_len, status, err_off, FLATE_HIP_SIZE_ONLY);
+}
+
+/* -- one long stream decoded in pieces: constructor + null test, and the three results of a read
+ * packed into one array (MoonBit passes no pointers to scalars) -- */
+flate_hip_inflate_stream *flate_hip_mbt_inflate_stream_new(flate_hip_ctx *c) {
+  flate_hip_inflate_stream *st = 0;
+  if (flate_hip_inflate_stream_open(c, &st) != FLATE_HIP_OK) return 0;
+  return st;
+}
+
+int flate_hip_mbt_inflate_stream_is_null(const flate_hip_inflate_stream *st) { return st == 0; }
+
+/* res[0] = bytes of `in` used, res[1] = bytes written to out, res[2] = err_off (int64 bits) */
+int flate_hip_mbt_inflate_stream_read(flate_hip_inflate_stream *st, const uint8_t *in, uint64_t in_len, int final_in,
+                                      uint8_t *out, uint64_t out_cap, uint64_t *res) {
+  int64_t eoff = -1;
+  const int rc = flate_hip_inflate_stream_read(st, in, in_len, final_in, out, out_cap, &res[0], &res[1], &eoff);
+  res[2] = (uint64_t)eoff;
+  return rc;
 }

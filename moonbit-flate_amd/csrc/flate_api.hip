@@ -97,8 +97,8 @@ struct flate_hip_ctx {
   // Host-pointer calls of the batch encoder: the batch is cut into host_groups groups of streams
   // and group g is compressed while group g+1 is copied in and the output of group g-1 is copied
   // out (two copy threads on two non-blocking streams).  0 = one copy in, compress, one copy out.
-  int host_groups = 4;
-  uint32_t host_group_streams = 4096;  // a group holds at least this many streams
+  int host_groups = 8;
+  uint32_t host_group_streams = 2048;  // a group holds at least this many streams (inflate: four times as many)
   // bounded waits of the persistent kernels (uq_pop, wait_count_kernel): polls before giving up
   // (a poll is one relaxed load + s_sleep, >= 0.4 us; a wave that is not running does not count)
   uint32_t spin_limit = 8u << 20;

@@ -351,87 +351,106 @@ struct BytesReader : ByteSource {  // @io.Buffer used as source
 };
 
 // &Reader::new(r) -> Decompressor (inflate.mbt:305) with read (:382-405) and close (:410-415).
-// The engine is a batch engine: the first read() pulls the whole source and decodes it in ONE pass
-// of known size -- a size-only pass first (FLATE_HIP_SIZE_ONLY: the decoder runs without storing and
-// reports what the stream inflates to), then the decode into exactly that much; no capacity is
-// guessed and nothing is decoded twice into a buffer that turns out too small.  The bytes and
-// errors then come out as the reference hands them out -- data first, the error (ioeof at a clean
-// end) together with the last bytes, nothing but the error afterwards.
+// As the reference's, this Reader holds a PIECE of the compressed stream and a piece of the output,
+// never the whole of either (flate_hip_inflate_stream_*: the decoder's state -- window, tables of the
+// block in progress, bit position, a copy that did not fit -- rests on the device between calls): a
+// 10 GB stream needs the two pieces, not 10 GB.  The bytes and errors come out as the reference hands
+// them out -- data first, the error (ioeof at a clean end) together with the last bytes, nothing but
+// the error afterwards.  (size_hint is accepted for source compatibility and ignored: nothing has to
+// be sized any more.)
 class Reader {
  public:
-  Reader(ByteSource &r, Engine &e, uint64_t size_hint = 0) : r_(&r), e_(e), hint_(size_hint) {}
+  Reader(ByteSource &r, Engine &e, uint64_t size_hint = 0, size_t in_piece = 1u << 20, size_t out_piece = 1u << 20)
+      : r_(&r), e_(e), in_piece_(in_piece < 4096 ? 4096 : in_piece), out_piece_(out_piece < 1 ? 1 : out_piece) {
+    (void)size_hint;
+  }
+  ~Reader() { flate_hip_inflate_stream_free(st_); }
+  Reader(const Reader &) = delete;
+  Reader &operator=(const Reader &) = delete;
 
   // Decompressor::reset (inflate.mbt:862-884; without a preset dictionary, which is outside the
   // scope table): forget everything and decode the stream `r` delivers next.
   void reset(ByteSource &r, uint64_t size_hint = 0) {
+    (void)size_hint;
     r_ = &r;
-    hint_ = size_hint;
-    decoded_ = false;
+    flate_hip_inflate_stream_free(st_);
+    st_ = nullptr;
+    in_.clear();
+    src_end_ = false;
     data_.clear();
     pos_ = 0;
     err_ = std::nullopt;
   }
 
   std::pair<int, Err> read(uint8_t *p, size_t n) {
-    if (!decoded_) decode();
-    if (pos_ < data_.size()) {
-      const size_t k = std::min(n, data_.size() - pos_);
-      std::copy(data_.begin() + pos_, data_.begin() + pos_ + k, p);
-      pos_ += k;
-      if (pos_ == data_.size()) return {(int)k, err_};  // :392-394
-      return {(int)k, std::nullopt};
+    for (;;) {
+      if (pos_ < data_.size()) {  // :384-396
+        const size_t k = std::min(n, data_.size() - pos_);
+        std::copy(data_.begin() + pos_, data_.begin() + pos_ + k, p);
+        pos_ += k;
+        if (pos_ == data_.size()) return {(int)k, err_};
+        return {(int)k, std::nullopt};
+      }
+      if (err_) return {0, err_};  // :397-400
+      step();
     }
-    return {0, err_};  // :397-400
   }
   Err close() {  // :410-415
     if (err_ && *err_ == ioeof()) return std::nullopt;
     return err_;
   }
+  // what this Reader holds at most: the two pieces (+ the decoder's 40 KiB on the device)
+  size_t resident_bytes() const { return in_.capacity() + data_.capacity(); }
 
  private:
-  void decode() {
-    decoded_ = true;
-    std::vector<uint8_t> src;
-    uint8_t tmp[4096];
-    for (;;) {
-      auto r = r_->read(tmp, sizeof tmp);
-      src.insert(src.end(), tmp, tmp + r.first);
+  // one call of the decoder: top the input piece up from the source, decode into the output piece
+  void step() {
+    if (!e_.ok()) {
+      err_ = make_error(e_, e_.status());
+      return;
+    }
+    if (!st_) {
+      const int rc = flate_hip_inflate_stream_open(e_.ctx(), &st_);
+      if (rc != 0) {
+        err_ = make_error(e_, rc);
+        return;
+      }
+    }
+    while (!src_end_ && in_.size() < in_piece_) {
+      const size_t at = in_.size();
+      in_.resize(in_piece_);
+      auto r = r_->read(in_.data() + at, in_piece_ - at);
+      in_.resize(at + (size_t)r.first);
       if (r.second) {
-        if (!(*r.second == ioeof())) {
+        if (!(*r.second == ioeof())) {  // the source's own error ends the stream (more_bits, :771-787)
           err_ = r.second;
           return;
         }
-        break;
+        src_end_ = true;
       }
     }
-    uint64_t cap = hint_;
-    if (cap == 0) {  // unknown size: ask the decoder
-      std::vector<uint64_t> sizes;
-      if (Err er = inflate_sizes(e_, {src}, sizes)) {
-        err_ = er;
-        return;
-      }
-      cap = sizes[0];
-    }
-    std::vector<Inflated> out;
-    Err er = decompress_batch(e_, {src}, {cap}, out);
-    if (!er && out[0].status == FLATE_HIP_E_OUT_TOO_SMALL && hint_ != 0) {  // a wrong hint: the exact size
-      std::vector<uint64_t> sizes;
-      er = inflate_sizes(e_, {src}, sizes);
-      if (!er) er = decompress_batch(e_, {src}, {sizes[0]}, out);
-    }
-    if (er) {
-      err_ = er;
-      return;
-    }
-    data_ = std::move(out[0].bytes);
-    err_ = out[0].err ? out[0].err : Err(ioeof());
+    data_.resize(out_piece_);
+    pos_ = 0;
+    uint64_t used = 0, got = 0;
+    int64_t eoff = -1;
+    const int rc = flate_hip_inflate_stream_read(st_, in_.data(), in_.size(), src_end_ ? 1 : 0, data_.data(),
+                                                 out_piece_, &used, &got, &eoff);
+    data_.resize((size_t)got);
+    in_.erase(in_.begin(), in_.begin() + (size_t)used);
+    if (rc == FLATE_HIP_STREAM_END) err_ = ioeof();
+    else if (rc == FLATE_HIP_E_CORRUPT) err_ = corrupt_input_error(eoff);
+    else if (rc == FLATE_HIP_E_UNEXPECTED_EOF) err_ = err_unexpected_eof();
+    else if (rc != 0) err_ = make_error(e_, rc);
+    else if (got == 0 && used == 0 && (src_end_ || in_.size() >= in_piece_))
+      err_ = make_error(e_, FLATE_HIP_E_INTERNAL);  // (no progress although the decoder has what it may ask for)
   }
   ByteSource *r_;
   Engine &e_;
-  uint64_t hint_;
-  bool decoded_ = false;
-  std::vector<uint8_t> data_;
+  size_t in_piece_, out_piece_;
+  flate_hip_inflate_stream *st_ = nullptr;
+  std::vector<uint8_t> in_;   // the bytes of the stream the decoder has not used yet
+  bool src_end_ = false;
+  std::vector<uint8_t> data_;  // decoded, not handed out yet (to_read, inflate.mbt:286)
   size_t pos_ = 0;
   Err err_;
 };

@@ -177,5 +177,36 @@ int main() {
     auto r2r = r2.read(back.data(), back.size());
     printf("wrong_hint %d %s\n", r2r.first, r2r.second ? r2r.second->msg.c_str() : "none");
   }
+  // Reader on a long stream with SMALL pieces: it never holds more than its two pieces (the reference's
+  // Decompressor holds a 32 KiB window and a 4-byte buffer, inflate.mbt:252-290)
+  {
+    std::vector<uint8_t> big(6 * 1000 * 1000);
+    uint32_t x = 4242;
+    for (size_t i = 0; i < big.size(); ++i) {
+      x = x * 1664525u + 1013904223u;
+      big[i] = (uint8_t)("a stream long enough not to fit "[(x >> 24) % 32]);
+    }
+    std::vector<std::vector<uint8_t>> cin{big}, cout;
+    Err ce = compress_batch(eng, cin, cout);
+    BytesReader src(cout.empty() ? std::vector<uint8_t>{} : cout[0]);
+    Reader r(src, eng, 0, 65536, 100000);
+    std::vector<uint8_t> piece(33333);
+    size_t total = 0, diff = 0, reads = 0, most = 0;
+    Err last;
+    for (;;) {
+      auto rr = r.read(piece.data(), piece.size());
+      for (int k = 0; k < rr.first; ++k) diff += total + (size_t)k >= big.size() || piece[k] != big[total + (size_t)k];
+      total += (size_t)rr.first;
+      ++reads;
+      most = std::max(most, r.resident_bytes());
+      if (rr.second) {
+        last = rr.second;
+        break;
+      }
+      if (reads > 100000) break;
+    }
+    printf("long_reader %s %zu %s %zu %d\n", ce ? ce->msg.c_str() : "none", total, last ? last->msg.c_str() : "none", diff,
+           most <= 65536 + 100000 + 8192 ? 1 : 0);
+  }
   return 0;
 }

@@ -303,12 +303,24 @@ def test_host_pointer_pipeline_matches_single_pass(oracle):
     try:
         e.set_option("host_pipeline_groups", 0)
         c0, o0 = e.deflate_batch(host, off)
-        for groups in (2, 3):
+        total = int(o0[-1])
+        for lanes, groups in ((1, 2), (2, 2), (2, 3), (1, 3)):
+            e.set_option("host_pipeline_lanes", lanes)
             e.set_option("host_pipeline_groups", groups)
             c1, o1 = e.deflate_batch(host, off)
-            assert np.array_equal(np.asarray(o0), np.asarray(o1)), groups
-            total = int(o0[-1])
-            assert np.array_equal(np.asarray(c0)[:total], np.asarray(c1)[:total]), groups
+            assert np.array_equal(np.asarray(o0), np.asarray(o1)), (lanes, groups)
+            assert np.array_equal(np.asarray(c0)[:total], np.asarray(c1)[:total]), (lanes, groups)
+        # page-locked buffers (flate_hip_host_register): the same calls, the same bytes
+        out_reg = np.empty(total + 4096, dtype=np.uint8)
+        with e.host_register(host), e.host_register(out_reg):
+            for lanes, groups in ((2, 3), (2, 0)):
+                e.set_option("host_pipeline_lanes", lanes)
+                e.set_option("host_pipeline_groups", groups)
+                out_reg[:] = 0
+                _, o2 = e.deflate_batch(host, off, out=out_reg)
+                assert np.array_equal(np.asarray(o0), np.asarray(o2)), (lanes, groups)
+                assert np.array_equal(np.asarray(c0)[:total], out_reg[:total]), (lanes, groups)
+        e.set_option("host_pipeline_lanes", 2)
         c = np.asarray(c1)
         for i in range(0, n, 509):
             assert bytes(c[int(o1[i]):int(o1[i + 1])]) == oracle.deflate(host[i * blen:(i + 1) * blen]), i

@@ -101,3 +101,6 @@ def test_host_mirror_matches_reference_behaviour(oracle):
     assert bytes.fromhex(lines["streamed_bytes"]) == want_long
     assert lines["streamed_back"] == "%d EOF 0" % len(long_)   # Reader without a size hint
     assert lines["wrong_hint"] == "%d EOF" % len(long_)        # ... and with a wrong one
+    # 6 MB through a Reader with a 64 KiB input piece and a 100 000-byte output piece: all bytes, ioeof
+    # with the last ones, and never more resident than the two pieces
+    assert lines["long_reader"] == "none 6000000 EOF 0 1"

@@ -98,7 +98,8 @@ def test_moonbit_stub_compiles_and_links_against_the_library(lib, tmp_path):
     stub = ctypes.CDLL(str(so))
     for name in ("flate_hip_mbt_ctx_new", "flate_hip_mbt_ctx_is_null",
                  "flate_hip_mbt_comm_new", "flate_hip_mbt_comm_is_null", "flate_hip_mbt_stream_new",
-                 "flate_hip_mbt_stream_is_null", "flate_hip_mbt_inflate_sizes"):
+                 "flate_hip_mbt_stream_is_null", "flate_hip_mbt_inflate_sizes", "flate_hip_mbt_inflate_stream_new",
+                 "flate_hip_mbt_inflate_stream_is_null", "flate_hip_mbt_inflate_stream_read"):
         assert hasattr(stub, name)
     # every symbol the .mbt binding names in an `extern "C" fn ... = "sym"` exists in the stub or
     # in the library, and the binding never copies a buffer on its way to C
