@@ -100,6 +100,11 @@ int flate_hip_set_stream(flate_hip_ctx *ctx, void *hip_stream);
  *   "overlap_sub_batches"  > 0: the entropy kernels of every sub-batch (queue order) run on a
  *                        second HIP stream as soon as the match finder has counted its streams
  *                        done (default 0: measured slower on MI355X)
+ *   "overlap_tail_streams"  k > 0: the uneven form of the same overlap -- the entropy kernels of all but
+ *                        the last k streams start while the persistent match-finder launch drains its
+ *                        last streams (every block publishes its finished streams once, when it is first
+ *                        handed a queue entry behind the split); single-window batches only (default 0:
+ *                        measured equal at best on MI355X, profiles/r04/README.md)
  *   "entropy_per_block"  -1 (default): the histogram and pack kernels run one wavefront per BLOCK
  *                        instead of per stream when the batch's streams have three or more blocks
  *                        on average; 0 = never; 1 = whenever every stream has a block

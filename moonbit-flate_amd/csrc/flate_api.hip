@@ -78,10 +78,15 @@ struct flate_hip_ctx {
   // measured slower on MI355X, profiles/r02/README.md -- the entropy kernels run 3x slower beside
   // the match finder than after it, so nothing is gained).
   int overlap_sub = 0;
+  // The UNEVEN form: two sub-batches, the last overlap_tail queue entries and everything in front of
+  // them.  The entropy kernels of the large first part start as soon as its last stream is done and run
+  // while the persistent match-finder launch drains (its blocks run dry over the last ~2.7 ms, one
+  // stream's time); the short second part follows the launch.  0 = off.
+  uint32_t overlap_tail = 0;
   uint32_t overlap_resident = 1024;  // LDS-table blocks while overlapping (4 per CU: leaves 32 KiB
                                      // of LDS per CU to the entropy kernels)
   hipStream_t ent_stream = nullptr;
-  hipEvent_t ev_ent = nullptr;
+  hipEvent_t ev_ent = nullptr, ev_lz = nullptr;  // (ev_lz: the match finder's launches have finished)
   std::vector<hipEvent_t> ent_ev;    // profiling: start/end of every sub-batch's entropy kernels
   DevBuf d_done;                     // overlap_sub counters + the running output size (u64)
   // window-granular scheduling of multi-window streams (lz77_kernels.hip, uq_*): on by default
@@ -306,7 +311,7 @@ int collect_timing(flate_hip_ctx *c, const bool used[FLATE_HIP_STAGE_COUNT]) {
 // overlap_sub > 0: count finished streams per sub-batch of that many queue entries in c->d_done
 // (the caller has checked that the launch is one persistent resident+guest launch in stream order)
 int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, const StagePlan &pl,
-             uint32_t flags, uint32_t overlap_sub = 0) {
+             uint32_t flags, uint32_t overlap_sub = 0, uint32_t done_split = 0) {
   const uint32_t n = pl.n_streams;
   int rc;
   if ((rc = ensure(c, c->d_in_off, ((size_t)n + 1) * 8))) return rc;
@@ -339,6 +344,7 @@ int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, cons
   P.queue_end = 0;
   P.done = overlap_sub ? (uint32_t *)c->d_done.p : nullptr;
   P.done_cap = overlap_sub ? kDoneCounters : 0u;
+  P.done_split = overlap_sub ? done_split : 0u;
   P.gtable_blocks = 0;
   P.spin_limit = c->spin_limit;
   P.inject_drop_push = c->inject_drop_push;
@@ -445,7 +451,7 @@ int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, cons
         (void)hipEventRecord(c->ev_fork, c->stream);
         (void)hipStreamWaitEvent(c->guest_stream, c->ev_fork, 0);
         uint32_t resident = c->resident_blocks < count ? c->resident_blocks : count;
-        if (overlap_sub && c->overlap_resident < resident) resident = c->overlap_resident;
+        if (overlap_sub && !done_split && c->overlap_resident < resident) resident = c->overlap_resident;
         if (multi) {
           hipLaunchKernelGGL(lz77_guest_kernel<true>, dim3((uint32_t)c->guest_blocks), dim3(64), 0,
                              c->guest_stream, G);
@@ -531,6 +537,7 @@ int flate_hip_init(int device, flate_hip_ctx **out) {
   c->stream = c->own_stream;
   if (hipStreamCreateWithFlags(&c->ent_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_ent, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_lz, hipEventDisableTiming) != hipSuccess ||
       hipStreamCreateWithFlags(&c->guest_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
@@ -592,6 +599,7 @@ void flate_hip_destroy(flate_hip_ctx *c) {
   if (c->guest_stream) (void)hipStreamDestroy(c->guest_stream);
   if (c->ent_stream) (void)hipStreamDestroy(c->ent_stream);
   if (c->ev_ent) (void)hipEventDestroy(c->ev_ent);
+  if (c->ev_lz) (void)hipEventDestroy(c->ev_lz);
   for (auto &e : c->ent_ev)
     if (e) (void)hipEventDestroy(e);
   release(c->d_done);
@@ -641,6 +649,8 @@ int flate_hip_set_option(flate_hip_ctx *c, const char *name, int64_t value) {
     c->window_units = (int)value;
   } else if (k == "overlap_sub_batches" && value >= 0 && value <= 64) {
     c->overlap_sub = (int)value;
+  } else if (k == "overlap_tail_streams" && value >= 0 && value <= 0x7fffffff) {
+    c->overlap_tail = (uint32_t)value;
   } else if (k == "overlap_resident_blocks" && value > 0 && value <= 65536) {
     c->overlap_resident = (uint32_t)value;
   } else if (k == "spin_limit_polls" && value > 0 && value <= 0x7fffffff) {
@@ -792,17 +802,27 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
   // of one kind), the output is not spliced (the splice needs every stream's size first) and the
   // wave kernels run (the single-lane debug kernel does not count its streams).
   const uint32_t list = (uint32_t)(pl.ids16.size() == n ? n : (pl.ids32.size() == n ? n : 0));
-  const bool overlap = c->overlap_sub > 0 && !spliced && list == n && n >= c->guest_min &&
+  // (single-window streams only: window units count their streams elsewhere, uq_pop)
+  const bool tail_form = c->overlap_tail > 0 && c->overlap_sub == 0 && n >= 4u * c->overlap_tail && pl.ids16.size() == n;
+  const bool overlap = (c->overlap_sub > 0 || tail_form) && !spliced && list == n && n >= c->guest_min &&
                        c->guest_blocks > 0 && !(flags & FLATE_HIP_LZ_SERIAL) &&
-                       n >= 4u * (uint32_t)c->overlap_sub;
+                       (tail_form || n >= 4u * (uint32_t)c->overlap_sub);
   c->overlapped = overlap;
   // sub-batch size: the power of two that gives at most overlap_sub sub-batches
   uint32_t sub = n;
-  if (overlap) {
+  if (overlap && !tail_form) {
     sub = 1;
     while ((uint64_t)sub * (uint32_t)c->overlap_sub < n) sub <<= 1;
   }
-  const uint32_t J = overlap ? (n + sub - 1) / sub : 1u;
+  // first stream of every sub-batch (and n)
+  std::vector<uint32_t> sb;
+  if (overlap && tail_form) {
+    sb = {0u, n - c->overlap_tail, n};
+  } else {
+    for (uint32_t f = 0; f < n; f += sub) sb.push_back(f);
+    sb.push_back(n);
+  }
+  const uint32_t J = overlap ? (uint32_t)sb.size() - 1u : 1u;
   if (overlap) {
     // the counters the match finder increments (P.done + (q >> done_shift), q < n): J of them
     if (J > kDoneCounters) return FLATE_HIP_E_INTERNAL;
@@ -814,10 +834,11 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
       c->ent_ev.push_back(e);
     }
   }
-  if ((rc = run_lz77(c, d_in, in_off, pl, flags, overlap ? sub : 0u))) return rc;
+  if ((rc = run_lz77(c, d_in, in_off, pl, flags, overlap ? sub : 0u, (overlap && tail_form) ? sb[1] : 0u))) return rc;
   // ev_fork sits on c->stream right in front of the match finder's launch, behind every upload
   // and memset the entropy kernels depend on
   if (overlap) (void)hipStreamWaitEvent(c->ent_stream, c->ev_fork, 0);
+  if (overlap && tail_form) (void)hipEventRecord(c->ev_lz, c->stream);  // (behind the join of both launches)
 
   HuffParams H{};
   H.in = d_in;
@@ -858,11 +879,14 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
     uint32_t *done = (uint32_t *)c->d_done.p;
     C.carry = (uint64_t *)((uint8_t *)c->d_done.p + kDoneCounters * 4);
     for (uint32_t j = 0; j < J; ++j) {
-      const uint32_t first = j * sub;
-      if (first >= n) break;
-      const uint32_t cnt = n - first < sub ? n - first : sub;
-      hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(1), 0, c->ent_stream, done + j, cnt,
-                         (int *)c->d_status.p, c->spin_limit);
+      const uint32_t first = sb[j];
+      const uint32_t cnt = sb[j + 1] - sb[j];
+      if (!cnt) continue;
+      if (tail_form && j == 1)  // the short last part simply follows the launch
+        (void)hipStreamWaitEvent(c->ent_stream, c->ev_lz, 0);
+      else
+        hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(1), 0, c->ent_stream, done + j, cnt,
+                           (int *)c->d_status.p, c->spin_limit);
       if (c->profiling) (void)hipEventRecord(c->ent_ev[2 * j], c->ent_stream);
       H.sid0 = first;
       C.first = first;
@@ -946,8 +970,8 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
     if ((rc = collect_timing(c, used))) return rc;
     if (c->profiling) {
       float tot = 0.f;
-      const uint32_t Jn = (n + sub - 1) / sub;
-      for (uint32_t j = 0; j < Jn; ++j) {
+      for (uint32_t j = 0; j < J; ++j) {
+        if (sb[j + 1] == sb[j]) continue;
         float ms = 0.f;
         HIP_TRY(c, hipEventElapsedTime(&ms, c->ent_ev[2 * j], c->ent_ev[2 * j + 1]));
         tot += ms;
@@ -1099,6 +1123,7 @@ static void lane_options(flate_hip_ctx *dst, const flate_hip_ctx *src) {
   dst->window_units = src->window_units;
   dst->entropy_per_block = src->entropy_per_block;
   dst->overlap_sub = src->overlap_sub;
+  dst->overlap_tail = src->overlap_tail;
   dst->overlap_resident = src->overlap_resident;
   dst->spin_limit = src->spin_limit;
   dst->profile_split = src->profile_split;

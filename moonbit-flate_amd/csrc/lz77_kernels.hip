@@ -735,12 +735,28 @@ FLATE_D void all_lanes_here(const LzParams &P, int lane) {
 }
 
 FLATE_D void stream_done_lane0(const LzParams &P, uint32_t q) {
-  if (!P.done) return;
+  if (!P.done || P.done_split) return;  // (done_split: see tail_done_lane0)
   const uint32_t k = q >> P.done_shift;
   if (k < P.done_cap)  // (the host sizes the counters for exactly this; anything else is a bug, not a fault)
     __hip_atomic_fetch_add(P.done + k, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   else
     atomicExch(P.status, kStatusBadIndex);
+}
+
+// The UNEVEN form of the overlap (P.done_split != 0: the entropy kernels of queue entries [0, done_split)
+// start while this launch drains its last streams).  A release per finished stream -- the write-back of
+// the XCD's whole L2 -- is what made the even form cost the match finder 0.7 ms; writing the records
+// through L2 instead cost 1.4 ms (measured: every batch's few records then leave as their own partial
+// sector).  A block takes its queue entries in increasing order, so it needs ONE release: when it is
+// first handed an entry at or behind the split (or none at all), every stream it has finished belongs
+// to the first part and nothing it will still finish does.  `pending` lives in lane 0.
+FLATE_D void tail_done_lane0(const LzParams &P, uint32_t prev, uint32_t q_next, uint32_t &pending) {
+  if (!P.done || !P.done_split) return;
+  if (prev != 0xffffffffu && prev < P.done_split) ++pending;
+  if (pending && q_next >= P.done_split) {
+    __hip_atomic_fetch_add(P.done, pending, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    pending = 0;
+  }
 }
 
 // ---------------------------------------------------------------------------------
@@ -921,6 +937,7 @@ __global__ __launch_bounds__(64) void lz77_wave_kernel(LzParams P) {
   // Either one block per stream (P.queue == null) or persistent: resident and guest blocks
   // share one queue (dynamic balance).  One call site keeps a single copy of the parser.
   uint32_t mine = 0, prev = 0xffffffffu;  // streams taken; the entry finished in the previous round
+  uint32_t pending = 0;                   // (lane 0) finished streams of the first part, not published yet
   for (bool first = true;; first = false) {
     uint32_t q;
     if (P.queue) {
@@ -928,6 +945,7 @@ __global__ __launch_bounds__(64) void lz77_wave_kernel(LzParams P) {
       if (lane == 0) {  // the ONE lane-0 block of the loop (see stream_done_lane0)
         if (prev != 0xffffffffu) stream_done_lane0(P, prev);
         q = atomicAdd(P.queue, 1u);
+        tail_done_lane0(P, prev, q, pending);
       }
       q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
       if (q >= P.queue_end) break;
@@ -970,11 +988,13 @@ __global__ __launch_bounds__(64) void lz77_guest_kernel(LzParams P) {
     return;
   }
   uint32_t prev = 0xffffffffu;
+  uint32_t pending = 0;  // (lane 0) finished streams of the first part, not published yet
   for (;;) {
     uint32_t q = 0;
     if (lane == 0) {  // the ONE lane-0 block of the loop (see stream_done_lane0)
       if (prev != 0xffffffffu) stream_done_lane0(P, prev);
       q = atomicAdd(P.queue, 1u);
+      tail_done_lane0(P, prev, q, pending);
     }
     q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
     if (q >= P.queue_end) break;

@@ -250,6 +250,22 @@ def test_overlapped_entropy_stage_is_bit_exact(oracle):
                 a = out[int(out_off[i]):int(out_off[i + 1])]
                 b = want[int(w_off[i]):int(w_off[i]) + int(w_len[i])]
                 assert a.size == b.size and np.array_equal(a, b), (sub, i)
+        # the UNEVEN form ("overlap_tail_streams"): everything but the last k streams is one sub-batch,
+        # gated on a count every block publishes once (when it is first handed an entry behind the split)
+        e.set_option("overlap_sub_batches", 0)
+        for tail in (1, 64, 200, 256):
+            e.set_option("overlap_tail_streams", tail)
+            for blocks in ((8, 8), (64, 256)):
+                e.set_option("resident_blocks", blocks[0])
+                e.set_option("guest_blocks", blocks[1])
+                out, out_off = e.deflate_batch(data, off)
+                for i in range(n):
+                    a = out[int(out_off[i]):int(out_off[i + 1])]
+                    b = want[int(w_off[i]):int(w_off[i]) + int(w_len[i])]
+                    assert a.size == b.size and np.array_equal(a, b), ("tail", tail, blocks, i)
+        e.set_option("overlap_tail_streams", 0)
+        e.set_option("resident_blocks", 1024)
+        e.set_option("guest_blocks", 1664)
         # multi-window streams: the match finder then hands windows between blocks (window units)
         # while the entropy stage of finished sub-batches already runs
         n2, blen2 = 192, 150000

@@ -58,8 +58,12 @@ while time.time() - t0 < budget:
     if rounds % 7 == 3:  # a uniform batch: the overlapped entropy stage is eligible
         eng.set_option("guest_min_streams", 1)
         eng.set_option("guest_blocks", 64)
-        eng.set_option("overlap_sub_batches", int(rng.choice([1, 4, 8, 16])))
         un = int(rng.integers(64, 400))
+        if rng.random() < 0.5:
+            eng.set_option("overlap_sub_batches", int(rng.choice([1, 4, 8, 16])))
+        else:  # the uneven form: one large first part, gated on the blocks' single counts
+            eng.set_option("overlap_sub_batches", 0)
+            eng.set_option("overlap_tail_streams", int(rng.integers(1, un // 4 + 1)))
         ulen = int(rng.choice([128, 5000, 65535, 65536, 70000, 140000]))
         ud = flate.synth("text", un, ulen, first_stream=int(rng.integers(1 << 20)))
         uo = flate.uniform_offsets(un, ulen)
@@ -70,6 +74,25 @@ while time.time() - t0 < budget:
                 "overlapped deflate stream %d differs (%s)" % (i, tag)
         streams += un
         nbytes += un * ulen
+        eng.set_option("overlap_tail_streams", 0)
+    if rounds % 5 == 1:  # one of the round's streams through the piecewise decoder (flate_hip_inflate_stream_*)
+        j = int(rng.integers(n))
+        cj = out[int(ooff[j]):int(ooff[j + 1])] if rounds % 7 != 3 else None
+        if cj is not None:
+            r = eng.open_inflate_stream()
+            got, pos, rc = [], 0, 0
+            piece, room = int(rng.integers(700, 70000)), int(rng.integers(1, 90000))
+            for _ in range(100000):
+                take = max(0, piece - r.pending_input)
+                chunk = cj[pos:pos + take]
+                pos += chunk.size
+                o, rc = r.feed(chunk, final=pos >= cj.size, room=room)
+                got.append(o)
+                if rc != 0:
+                    break
+            r.free()
+            want_j = data[int(off[j]):int(off[j + 1])].tobytes()
+            assert rc == 1 and b"".join(x.tobytes() for x in got) == want_j, "piecewise inflate of stream %d (%s)" % (j, tag)
     rounds += 1
     streams += n
     nbytes += int(off[-1])
