@@ -50,7 +50,7 @@ struct flate_hip_ctx {
   // entropy stage with one wavefront per BLOCK instead of per stream: -1 = when the batch's streams
   // have three or more blocks on average (multi-window streams), 0 = never, 1 = whenever possible
   int entropy_per_block = -1;
-  DevBuf d_istatus, d_ierr, d_debug, d_gtables, d_queue;
+  DevBuf d_istatus, d_ierr, d_debug, d_gtables, d_queue, d_simt_lens;
   hipStream_t guest_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int guest_blocks = 0;      // 0 = guest kernel off
@@ -592,7 +592,7 @@ void flate_hip_destroy(flate_hip_ctx *c) {
   for (DevBuf *b : {&c->scan_tab, &c->d_in, &c->d_out, &c->d_in_off, &c->d_chunk_base, &c->d_ids16,
                     &c->d_ids32, &c->d_matches, &c->d_nmatch, &c->d_ntok, &c->d_blk_base,
                     &c->d_blk_hist, &c->d_blk_cl, &c->d_blk_hdr, &c->d_blk_meta, &c->d_tile_meta, &c->d_blk_sid, &c->d_slot_off, &c->d_out_len, &c->d_out_off, &c->d_status, &c->d_istatus,
-                    &c->d_ierr, &c->d_debug, &c->d_gtables, &c->d_queue})
+                    &c->d_ierr, &c->d_debug, &c->d_gtables, &c->d_queue, &c->d_simt_lens})
     release(*b);
   for (auto &e : c->ev)
     if (e) (void)hipEventDestroy(e);
@@ -1751,12 +1751,26 @@ static int inflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
       // streams per wavefront: as many as still leave four wavefronts (one per SIMD) per CU
       int lpw = c->inflate_lanes;
       if (lpw == 0) lpw = n >= 256u * c->num_cus ? 64 : (n >= 128u * c->num_cus ? 32 : 16);
-      if (lpw == 64)
-        hipLaunchKernelGGL(inflate_simt_kernel<64>, dim3((n + 63) / 64), dim3(64), inflate_simt_lds_bytes(64), c->stream, I);
-      else if (lpw == 32)
-        hipLaunchKernelGGL(inflate_simt_kernel<32>, dim3((n + 31) / 32), dim3(64), inflate_simt_lds_bytes(32), c->stream, I);
-      else
-        hipLaunchKernelGGL(inflate_simt_kernel<16>, dim3((n + 15) / 16), dim3(64), inflate_simt_lds_bytes(16), c->stream, I);
+      const uint32_t sblocks = (n + (uint32_t)lpw - 1) / (uint32_t)lpw;
+      // A CU holds eight of these wavefronts (320 B of LDS per lane): a batch of more blocks than
+      // that runs in ROUNDS, and a lane's rate depends little on how full the chip is -- so the rounds
+      // are made equal (196608 streams: two launches of 98304 = 94 ms, against 60 + 47 for a full
+      // round and a third of one).
+      const uint32_t slots = 8u * c->num_cus;
+      const uint32_t rounds = (sblocks + slots - 1) / slots;
+      const uint32_t per = (sblocks + rounds - 1) / (rounds ? rounds : 1u);
+      if ((rc = ensure(c, c->d_simt_lens, inflate_simt_lens_bytes(per)))) return rc;
+      I.simt_lens = (uint32_t *)c->d_simt_lens.p;
+      for (uint32_t b0 = 0; b0 < sblocks; b0 += per) {
+        const uint32_t nb = sblocks - b0 < per ? sblocks - b0 : per;
+        I.sid0 = b0 * (uint32_t)lpw;
+        if (lpw == 64)
+          hipLaunchKernelGGL(inflate_simt_kernel<64>, dim3(nb), dim3(64), inflate_simt_lds_bytes(64), c->stream, I);
+        else if (lpw == 32)
+          hipLaunchKernelGGL(inflate_simt_kernel<32>, dim3(nb), dim3(64), inflate_simt_lds_bytes(32), c->stream, I);
+        else
+          hipLaunchKernelGGL(inflate_simt_kernel<16>, dim3(nb), dim3(64), inflate_simt_lds_bytes(16), c->stream, I);
+      }
     }
     else
       hipLaunchKernelGGL(inflate_kernel, dim3(n), dim3(64), 0, c->stream, I);

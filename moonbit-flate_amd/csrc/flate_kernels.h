@@ -126,6 +126,8 @@ struct InfParams {
   const uint64_t *bit_off;
   uint64_t in_len;
   uint32_t size_only;  // inflate_kernel: decode and count, store nothing (FLATE_HIP_SIZE_ONLY)
+  uint32_t *simt_lens; // inflate_simt_kernel: per-lane scratch of the header being parsed (inflate_simt_lens_bytes)
+  uint32_t sid0;       // inflate_simt_kernel: first stream of this launch (a batch of several rounds)
 };
 
 __global__ void lz77_serial_kernel(LzParams P);
@@ -196,6 +198,7 @@ struct SpliceParams {
 __global__ void splice_scan_kernel(SpliceParams P);
 __global__ void splice_zero_kernel(SpliceParams P, uint8_t *out);
 size_t inflate_simt_lds_bytes(int lanes_per_wave);  // dynamic LDS of that launch
+size_t inflate_simt_lens_bytes(uint32_t blocks);    // global scratch of that launch (InfParams::simt_lens)
 
 }  // namespace flate
 

@@ -561,15 +561,24 @@ namespace flate {
 
 namespace {
 
-// per-lane LDS layout, in u16 entries: 592 bytes per lane, so four 64-lane wavefronts fit one CU.
-// There is no lookup table: a code is resolved canonically (shuff_sym), which needs only the
-// symbols sorted by (length, symbol) -- one byte each -- and two small per-length arrays.
+// per-lane LDS layout, in u16 entries: 320 bytes per lane, so EIGHT 64-lane wavefronts fit one CU (two
+// per SIMD; 8 x 64 x 320 B = the CU's 160 KiB exactly) and 131072 streams -- 8 GiB of 64 KiB streams,
+// BASELINE config 5 -- are one round of 512 lanes per CU.  There is no lookup table: a code is
+// resolved canonically (canon_decode), which needs only the symbols sorted by (length, symbol) -- one
+// byte each -- and small per-length arrays.  LDS holds what the literal/length code needs on every
+// symbol: its sorted list (288 B) and delta[16] (32 B).  The rest lives in REGISTERS: the distance
+// code's sorted list (30 symbols, four per register), and the two per-length arrays that a lookup
+// reaches through the length comparison itself (PerLen: no dynamic register index, no select chain).
+// Round 3 kept everything, and the header's code lengths, in LDS: 592 B per lane, four wavefronts.
 constexpr int kOffLitSorted = 0;                      // 288 symbols & 0xff, two per u16
-constexpr int kOffDistSorted = kOffLitSorted + 144;   // 32 symbols (also the code-length decoder)
-constexpr int kOffLitMeta = kOffDistSorted + 16;      // delta[16], thr[16]
-constexpr int kOffDistMeta = kOffLitMeta + 32;        // delta[16]
-constexpr int kOffLens = kOffDistMeta + 16;           // 352 code lengths (32 + 286 + 30 used), four per u16
-constexpr int kLaneWords = kOffLens + 88;             // 296
+constexpr int kOffLitMeta = kOffLitSorted + 144;      // delta[16]
+constexpr int kLaneWords = kOffLitMeta + 16;          // 160
+// The 352 code lengths of a block header while it is parsed (32 + 286 + 30 used, four bits each) do NOT
+// live in LDS: they are touched by the header states only -- once per block, a few hundred steps
+// against thousands of symbol steps -- and their 176 bytes per lane were what held a CU to four
+// wavefronts.  Every lane has a slice of global scratch
+// instead (InfParams::simt_lens, kLensDwords dwords per lane).
+constexpr int kLensDwords = 48;
 
 enum SState { S_BLOCK = 0, S_DYN_LENS, S_SYM, S_DIST, S_STORED, S_DONE };
 // literal/length symbols one lane may decode per step (measured on config 5: 2 -4 %, 3 = 4, 6 -9 %)
@@ -580,6 +589,31 @@ typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 struct Limits {
   us2 p[8];
 };
+// A per-length array V[1..15] (16-bit values) in eight registers, read WITHOUT an index: the length of
+// a code is 16 - #{k : lim[k] > c15}, and with e[k] = V[k+1] - V[k+2] (V[16] = 0) the sum of e[k] over
+// exactly those k telescopes to V[len] (mod 2^16) -- one packed multiply-add per pair of limits, next
+// to the compare that counts them (canon_decode).
+struct PerLen {
+  us2 e[8];
+};
+// the distance code (and, while a header is read, the code-length code): sorted symbols + delta[]
+struct DistRegs {
+  uint32_t sorted[8];  // 32 symbols of 8 bits
+  PerLen delta;
+};
+// sorted[i & 31] without a dynamic register index
+FLATE_D uint32_t dist_sorted_get(const DistRegs &D, uint32_t i) {
+  // (selects over VALUES read first and made opaque: a select between two fields becomes a load from
+  // a selected address -- dynamic indexing -- and that keeps the whole struct in scratch memory)
+  uint32_t s0 = D.sorted[0], s1 = D.sorted[1], s2 = D.sorted[2], s3 = D.sorted[3];
+  uint32_t s4 = D.sorted[4], s5 = D.sorted[5], s6 = D.sorted[6], s7 = D.sorted[7];
+  asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "+v"(s4), "+v"(s5), "+v"(s6), "+v"(s7));
+  const uint32_t w = (i >> 2) & 7u;
+  const uint32_t a = (w & 1u) ? s1 : s0, b = (w & 1u) ? s3 : s2;
+  const uint32_t c = (w & 1u) ? s5 : s4, d = (w & 1u) ? s7 : s6;
+  const uint32_t e = (w & 2u) ? b : a, f = (w & 2u) ? d : c;
+  return (((w & 4u) ? f : e) >> ((i & 3u) * 8u)) & 0xffu;
+}
 
 template <int LPW>
 struct LaneLds {
@@ -591,11 +625,15 @@ struct LaneLds {
     uint16_t &w = base[(off + (int)(i >> 1)) * LPW];
     w = (uint16_t)((i & 1u) ? ((w & 0x00ffu) | (v << 8)) : ((w & 0xff00u) | v));
   }
-  FLATE_D uint32_t len_get(int i) const { return (base[(kOffLens + (i >> 2)) * LPW] >> ((i & 3) * 4)) & 15u; }
+};
+
+struct LaneLens {
+  uint32_t *g;  // this lane's kLensDwords dwords
+  FLATE_D uint32_t len_get(int i) const { return (g[i >> 3] >> ((i & 7) * 4)) & 15u; }
   FLATE_D void len_set(int i, uint32_t v) const {
-    uint16_t &w = base[(kOffLens + (i >> 2)) * LPW];
-    const int sh = (i & 3) * 4;
-    w = (uint16_t)((w & ~(15u << sh)) | (v << sh));
+    const int sh = (i & 7) * 4;
+    const uint32_t w = g[i >> 3];
+    g[i >> 3] = (w & ~(15u << sh)) | (v << sh);
   }
 };
 
@@ -697,21 +735,31 @@ struct DecInit {
   Limits lim;
   int mn;
   bool ok;
+  PerLen aux;          // LIT: thr[] (first code of each length whose symbol is >= 256); else delta[]
+  uint32_t sorted[8];  // !LIT: the sorted symbols (registers); LIT: the list is in LDS
 };
-template <bool THR, class LL>
-FLATE_D DecInit sdec_init(const LL &L, int lens_at, int n, int sorted_off, int meta_off) {
+template <bool LIT, class LL>
+FLATE_D DecInit sdec_init(const LL &L, const LaneLens &N, int lens_at, int n) {
   DecInit R;
   R.ok = true;
   uint32_t lim[16];
   uint32_t cnt[16], low[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) cnt[k] = low[k] = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    R.sorted[k] = 0;
+    R.aux.e[k] = us2{0, 0};
+  }
+  uint32_t lw = 0;  // the dword of eight lengths under the cursor (one global load per eight symbols)
   for (int i = 0; i < n; ++i) {
-    const uint32_t l = L.len_get(lens_at + i);
+    const int idx = lens_at + i;
+    if (i == 0 || (idx & 7) == 0) lw = N.g[idx >> 3];
+    const uint32_t l = (lw >> ((idx & 7) * 4)) & 15u;
 #pragma unroll
     for (int k = 1; k < 16; ++k) {
       cnt[k] += l == (uint32_t)k ? 1u : 0u;
-      if (THR) low[k] += (l == (uint32_t)k && i < 256) ? 1u : 0u;
+      if (LIT) low[k] += (l == (uint32_t)k && i < 256) ? 1u : 0u;
     }
   }
   int mn = 0, mx = 0;
@@ -726,17 +774,25 @@ FLATE_D DecInit sdec_init(const LL &L, int lens_at, int n, int sorted_off, int m
   if (mx == 0) return R;  // empty tree (:143-145): every lookup is corrupt
   lim[15] = 0;  // pad: never above the code bits
   uint32_t next_off[16];
-  uint32_t code = 0, off = 0;
+  // the per-length array V[k] that goes to registers (thr / delta) as ev[j] = V[j + 1] - V[j + 2],
+  // j = 0 .. 14 (limit j separates lengths <= j + 1 from the longer ones), V[16] = 0
+  uint32_t ev[16];
+  ev[15] = 0;
+  uint32_t code = 0, off = 0, vprev = 0;
 #pragma unroll
   for (int k = 1; k < 16; ++k) {  // :148-154
     code <<= 1;
-    L.set(meta_off + k, (off - code) & 0xffffu);
-    if (THR) L.set(meta_off + 16 + k, code + low[k]);
+    const uint32_t delta = (off - code) & 0xffffu;
+    if (LIT) L.set(kOffLitMeta + k, delta);
+    const uint32_t v = LIT ? code + low[k] : delta;
+    if (k >= 2) ev[k - 2] = (vprev - v) & 0xffffu;
+    vprev = v;
     next_off[k] = off;
     code += cnt[k];
     off += cnt[k];
     lim[k - 1] = code << (15 - k);
   }
+  ev[14] = vprev & 0xffffu;
   {  // completeness (:161), from min to max as the reference computes it
     uint32_t cc = 0;
 #pragma unroll
@@ -748,15 +804,27 @@ FLATE_D DecInit sdec_init(const LL &L, int lens_at, int n, int sorted_off, int m
     }
   }
 #pragma unroll
-  for (int k = 0; k < 8; ++k) R.lim.p[k] = us2{(unsigned short)lim[2 * k], (unsigned short)lim[2 * k + 1]};
+  for (int k = 0; k < 8; ++k) {
+    R.lim.p[k] = us2{(unsigned short)lim[2 * k], (unsigned short)lim[2 * k + 1]};
+    R.aux.e[k] = us2{(unsigned short)ev[2 * k], (unsigned short)ev[2 * k + 1]};
+  }
+  lw = 0;
   for (int i = 0; i < n; ++i) {
-    const uint32_t l = L.len_get(lens_at + i);
+    const int idx = lens_at + i;
+    if (i == 0 || (idx & 7) == 0) lw = N.g[idx >> 3];
+    const uint32_t l = (lw >> ((idx & 7) * 4)) & 15u;
     if (!l) continue;
     uint32_t at = 0;
 #pragma unroll
     for (int k = 1; k < 16; ++k)
       if (l == (uint32_t)k) at = next_off[k]++;
-    L.set8(sorted_off, at, (uint32_t)i & 0xffu);
+    if (LIT) {
+      L.set8(kOffLitSorted, at, (uint32_t)i & 0xffu);
+    } else {  // (at < 32: the distance code has 30 symbols, the code-length code 19)
+      const uint32_t put = ((uint32_t)i & 0xffu) << ((at & 3u) * 8u);
+#pragma unroll
+      for (int w = 0; w < 8; ++w) R.sorted[w] |= (at >> 2) == (uint32_t)w ? put : 0u;
+    }
   }
   return R;
 }
@@ -764,31 +832,50 @@ FLATE_D DecInit sdec_init(const LL &L, int lens_at, int n, int sorted_off, int m
 // Canonical decode of one code, no loop and no branch: returns the code length (16 = no such
 // code, also for an empty tree) and the symbol.  The length is 16 - the number of limits above the
 // next 15 bits (MSB first), counted two at a time with packed 16-bit arithmetic (c15 - lim is
-// negative exactly when lim is above); the symbol sits at code + (offs - first) in the sorted
-// list.  w = the bit window (LSB = next bit).
-template <bool THR, class LL>
-FLATE_D uint32_t canon_decode(const LL &L, uint32_t w, int sorted_off, int meta_off, const Limits &lim,
-                              uint32_t *sym_out) {
+// negative exactly when lim is above); the same 0/1 pairs, multiplied into a PerLen, deliver that
+// length's entry of a per-length array.  The symbol sits at code + delta[len] in the sorted list.
+// w = the bit window (LSB = next bit).
+FLATE_D uint32_t canon_len(uint32_t w, const Limits &lim, const PerLen &aux, uint32_t *c15_out, uint32_t *aux_out) {
   const uint32_t c15 = __brev(w) >> 17;
   const us2 c2 = us2{(unsigned short)c15, (unsigned short)c15};
-  us2 above = us2{0, 0};
+  us2 above = us2{0, 0}, acc = us2{0, 0};
 #pragma unroll
-  for (int k = 0; k < 8; ++k) above += (c2 - lim.p[k]) >> 15;
-  const uint32_t len = 16u - above.x - above.y;
+  for (int k = 0; k < 8; ++k) {
+    const us2 ind = (c2 - lim.p[k]) >> 15;
+    above += ind;
+    acc += ind * aux.e[k];
+  }
+  *c15_out = c15;
+  *aux_out = ((uint32_t)acc.x + (uint32_t)acc.y) & 0xffffu;
+  return 16u - above.x - above.y;
+}
+// literal/length code: sorted list and delta[] in LDS, thr[] in registers
+template <class LL>
+FLATE_D uint32_t canon_decode_lit(const LL &L, uint32_t w, const Limits &lim, const PerLen &thr, uint32_t *sym_out) {
+  uint32_t c15, t;
+  const uint32_t len = canon_len(w, lim, thr, &c15, &t);
   const uint32_t lc = len > 15u ? 15u : len;
   const uint32_t code = c15 >> (15u - lc);
-  uint32_t sym = L.get8(sorted_off, (code + L.get(meta_off + (int)lc)) & 0xffffu);
-  if (THR) sym |= code >= L.get(meta_off + 16 + (int)lc) ? 256u : 0u;
+  uint32_t sym = L.get8(kOffLitSorted, (code + L.get(kOffLitMeta + (int)lc)) & 0xffffu);
+  sym |= code >= t ? 256u : 0u;
   *sym_out = sym;
+  return len;
+}
+// distance code / code-length code: everything in registers
+FLATE_D uint32_t canon_decode_dist(uint32_t w, const Limits &lim, const DistRegs &D, uint32_t *sym_out) {
+  uint32_t c15, delta;
+  const uint32_t len = canon_len(w, lim, D.delta, &c15, &delta);
+  const uint32_t lc = len > 15u ? 15u : len;
+  const uint32_t code = c15 >> (15u - lc);
+  *sym_out = dist_sorted_get(D, code + delta);
   return len;
 }
 
 // huff_sym (inflate.mbt:803-854) for the block-header states; the hot states inline the same
 // checks without branches.  Returns the symbol, or -1 with *err set.
-template <class LL>
-FLATE_D int shuff_sym(SBits &b, const LL &L, int sorted_off, int meta_off, int dmin, const Limits &lim, int *err) {
+FLATE_D int shuff_sym(SBits &b, const DistRegs &D, int dmin, const Limits &lim, int *err) {
   uint32_t sym;
-  const uint32_t len = canon_decode<false>(L, sb_peek(b), sorted_off, meta_off, lim, &sym);
+  const uint32_t len = canon_decode_dist(sb_peek(b), lim, D, &sym);
   if (!sb_need(b, (uint32_t)dmin)) {
     *err = E_EOF;
     return -1;
@@ -816,9 +903,10 @@ template <int LPW>
 __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
   const int lane = threadIdx.x;
   const int lds_lane = lane < LPW ? lane : 0;
-  const uint32_t sid = blockIdx.x * (uint32_t)LPW + (uint32_t)lane;
+  const uint32_t sid = P.sid0 + blockIdx.x * (uint32_t)LPW + (uint32_t)lane;
   const bool have = lane < LPW && sid < P.n_streams;
   const LaneLds<LPW> L = {simt_lds + lds_lane};
+  const LaneLens N = {P.simt_lens + ((size_t)blockIdx.x * 64 + (size_t)lane) * kLensDwords};
 
   // the lane's state (plain locals: they must live in registers)
   SBits b;
@@ -829,6 +917,8 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
   int lit_min, dist_min, cl_min;
   int hdr_i, hdr_n, hdr_nlit, hdr_ndist;
   Limits lit_lim, dist_lim;       // dist_lim also serves the code-length code
+  PerLen lit_thr;                 // thr[] of the literal/length code
+  DistRegs dreg;                  // the distance code (the code-length code while a header is read)
   uint32_t match_len;             // S_DIST: the length decoded by S_SYM
   uint32_t copy_len, copy_dist;   // LZ77 copy in flight (S_STORED: raw bytes left, in copy_len)
   // its next (up to) 16 source bytes, requested a step ahead.  16 rather than 8: one step (and one
@@ -877,7 +967,10 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
   lit_min = dist_min = cl_min = 0;
   hdr_i = hdr_n = hdr_nlit = hdr_ndist = 0;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) lit_lim.p[k] = dist_lim.p[k] = us2{0, 0};
+  for (int k = 0; k < 8; ++k) {
+    lit_lim.p[k] = dist_lim.p[k] = lit_thr.e[k] = dreg.delta.e[k] = us2{0, 0};
+    dreg.sorted[k] = 0;
+  }
   match_len = copy_len = copy_dist = 0;
   pend_lo = pend_hi = 0;
   lit_lo = lit_hi = lit_n = 0;
@@ -889,25 +982,29 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
     if (state == S_DYN_LENS) {  // inflate.mbt:471-536, one code-length symbol per step
       if (hdr_i >= hdr_n) {
         // (the code-length decoder sits in the distance slots: the literal code is built first)
-        const DecInit lit = sdec_init<true>(L, 32, hdr_nlit, kOffLitSorted, kOffLitMeta);
-        const DecInit dst = sdec_init<false>(L, 32 + hdr_nlit, hdr_ndist, kOffDistSorted, kOffDistMeta);
+        const DecInit lit = sdec_init<true>(L, N, 32, hdr_nlit);
+        const DecInit dst = sdec_init<false>(L, N, 32 + hdr_nlit, hdr_ndist);
         lit_lim = lit.lim;
         lit_min = lit.mn;
+        lit_thr = lit.aux;
         dist_lim = dst.lim;
         dist_min = dst.mn;
+        dreg.delta = dst.aux;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dreg.sorted[k] = dst.sorted[k];
         if (!lit.ok || !dst.ok) {
           serr = E_CORRUPT;
         } else {
-          const int eob = (int)L.len_get(32 + 256);
+          const int eob = (int)N.len_get(32 + 256);
           if (lit_min < eob) lit_min = eob;  // :542-544
           state = S_SYM;
         }
       } else {
         sb_sync(b);
-        const int x = shuff_sym(b, L, kOffDistSorted, kOffDistMeta, cl_min, dist_lim, &serr);
+        const int x = shuff_sym(b, dreg, cl_min, dist_lim, &serr);
         if (x >= 0) {
           if (x < 16) {
-            L.len_set(32 + hdr_i, (uint32_t)x);
+            N.len_set(32 + hdr_i, (uint32_t)x);
             ++hdr_i;
           } else {
             int rep = x == 18 ? 11 : 3;
@@ -916,7 +1013,7 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
             if (x == 16 && hdr_i == 0) {
               serr = E_CORRUPT;
             } else {
-              if (x == 16) fill = L.len_get(32 + hdr_i - 1);
+              if (x == 16) fill = N.len_get(32 + hdr_i - 1);
               const uint32_t w = sb_peek(b);
               if (!sb_need(b, nb)) {
                 serr = E_EOF;
@@ -926,7 +1023,7 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
                 if (hdr_i + rep > hdr_n) {
                   serr = E_CORRUPT;
                 } else {
-                  for (int j = 0; j < rep; ++j) L.len_set(32 + hdr_i + j, fill);
+                  for (int j = 0; j < rep; ++j) N.len_set(32 + hdr_i + j, fill);
                   hdr_i += rep;
                 }
               }
@@ -968,14 +1065,19 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
             }
           }
         } else if (typ == 1) {  // fixed tables (:886-939); distances are 5-bit codes
-          for (int i = 0; i < 288; ++i) L.len_set(i, i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8)));
-          for (int i = 0; i < 32; ++i) L.len_set(288 + i, 5);
-          const DecInit lit = sdec_init<true>(L, 0, 288, kOffLitSorted, kOffLitMeta);
-          const DecInit dst = sdec_init<false>(L, 288, 32, kOffDistSorted, kOffDistMeta);
+          // lengths 8 x 144, 9 x 112, 7 x 24, 8 x 8, then 5 x 32: whole dwords of eight
+          for (int i = 0; i < 40; ++i)
+            N.g[i] = i < 18 ? 0x88888888u : (i < 32 ? 0x99999999u : (i < 35 ? 0x77777777u : (i < 36 ? 0x88888888u : 0x55555555u)));
+          const DecInit lit = sdec_init<true>(L, N, 0, 288);
+          const DecInit dst = sdec_init<false>(L, N, 288, 32);
           lit_lim = lit.lim;
           lit_min = lit.mn;
+          lit_thr = lit.aux;
           dist_lim = dst.lim;
           dist_min = dst.mn;
+          dreg.delta = dst.aux;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) dreg.sorted[k] = dst.sorted[k];
           state = S_SYM;
         } else if (!sb_need(b, 14)) {  // read_huffman (:429-470)
           serr = E_EOF;
@@ -989,20 +1091,23 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
           } else {
             sb_take(b, 14);
             sb_sync(b);
-            for (int i = 0; i < kNumCodes; ++i) L.len_set(i, 0);
+            N.g[0] = N.g[1] = N.g[2] = 0;  // the 19 lengths of the code-length code
             for (int i = 0; i < nclen && !serr; ++i) {
               if (!sb_need(b, 3)) {
                 serr = E_EOF;
               } else {
-                L.len_set(kCodeOrder[i], sb_peek(b) & 7u);
+                N.len_set(kCodeOrder[i], sb_peek(b) & 7u);
                 sb_take(b, 3);
                 sb_sync(b);
               }
             }
             if (!serr) {
-              const DecInit cl = sdec_init<false>(L, 0, kNumCodes, kOffDistSorted, kOffDistMeta);
+              const DecInit cl = sdec_init<false>(L, N, 0, kNumCodes);
               dist_lim = cl.lim;
               cl_min = cl.mn;
+              dreg.delta = cl.aux;
+#pragma unroll
+              for (int k = 0; k < 8; ++k) dreg.sorted[k] = cl.sorted[k];
               if (!cl.ok) {
                 serr = E_CORRUPT;
               } else {
@@ -1081,7 +1186,7 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
       if (go) {
         const uint32_t w = sb_peek(b);  // >= 21 real bits
         uint32_t sym;
-        const uint32_t len = canon_decode<true>(L, w, kOffLitSorted, kOffLitMeta, lit_lim, &sym);
+        const uint32_t len = canon_decode_lit(L, w, lit_lim, lit_thr, &sym);
         const bool nocode = len > 15u;
         // :590-617 in closed form: 257..264 -> 3..10; 265..284 -> ((4|(x&3)) << n) + 3, x = sym-261
         const uint32_t x = sym - 261u;
@@ -1126,7 +1231,7 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
     if (state == S_DIST && last_chunk && off2 <= 67u) {
       const uint32_t w = sb_window(b, off2);  // >= 29 real bits
       uint32_t d;
-      const uint32_t len = canon_decode<false>(L, w, kOffDistSorted, kOffDistMeta, dist_lim, &d);
+      const uint32_t len = canon_decode_dist(w, dist_lim, dreg, &d);
       const bool nocode = len > 15u;
       const uint32_t nb = d < 4u ? 0u : (d - 2u) >> 1;
       const uint32_t dist =
@@ -1269,5 +1374,6 @@ template __global__ void inflate_simt_kernel<32>(InfParams);
 template __global__ void inflate_simt_kernel<16>(InfParams);
 
 size_t inflate_simt_lds_bytes(int lanes_per_wave) { return (size_t)kLaneWords * lanes_per_wave * sizeof(uint16_t); }
+size_t inflate_simt_lens_bytes(uint32_t blocks) { return (size_t)blocks * 64 * kLensDwords * sizeof(uint32_t); }
 
 }  // namespace flate

@@ -256,3 +256,28 @@ def test_host_pointer_pipeline_matches_single_pass(oracle):
             assert want == int(got[3][i]) and eoff == int(got[4][i]), (i, rc, eoff, int(got[3][i]), int(got[4][i]))
     finally:
         e.close()
+
+
+def test_lane_per_stream_decoder_in_several_rounds(oracle):
+    # more streams than the chip holds lanes (8 wavefronts x 64 lanes per CU): the lane-per-stream
+    # decoder runs in equal rounds, each launch starting at its own first stream
+    rng = np.random.default_rng(23)
+    kinds = [b"", b"a", b"abcabcabcabc" * 9, bytes(rng.integers(0, 256, 90, dtype=np.uint8)), b"\0" * 300,
+             bytes(rng.integers(97, 101, 200, dtype=np.uint8))]
+    comp_kinds = [oracle.deflate(np.frombuffer(k, np.uint8)) for k in kinds]
+    n = 8 * 256 * 64 + 5000
+    pick = rng.integers(0, len(kinds), n)
+    blobs = [comp_kinds[int(k)] for k in pick]
+    data, off = _pack(blobs)
+    sizes = np.array([len(kinds[int(k)]) for k in pick], dtype=np.uint64)
+    e = flate.FlateEngine(0)
+    try:
+        e.set_option("inflate_simt_min_streams", 0)
+        e.set_option("inflate_spec", 0)
+        e.set_option("inflate_lanes", 64)
+        out, ooff, olen, status, _ = e.inflate_batch(data, off, sizes)
+        assert (status == 0).all() and (olen == sizes).all()
+        want = b"".join(kinds[int(k)] for k in pick)
+        assert bytes(out[:int(ooff[-1])]) == want
+    finally:
+        e.close()
