@@ -635,8 +635,8 @@ def bench_inflate(args, env, d_in, in_off, n, blen, host=None, steps=None, warmu
                                % ("ONE spliced stream of " if args.spliced else "", n, blen, args.kind),
                    "compressed_bytes_per_gpu": clen,
                    "stage_ms": {"inflate": round(k_ms, 3)}, "step_ms": summarize(step_s)},
-        # (the library's choice at its default options: the sub-block decoder below 36864 streams)
-        "roofline": {"bound": "hbm", "kernel": "inflate_simt_kernel" if n >= 36864 else "inflate_spec_kernel",
+        # (the library's choice at its default options: the sub-block decoder below 45056 streams)
+        "roofline": {"bound": "hbm", "kernel": "inflate_simt_kernel" if n >= 45056 else "inflate_spec_kernel",
                      "achieved": round(achieved, 2),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                      "traffic": traffic, "traffic_source": traffic_src},

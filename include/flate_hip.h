@@ -113,7 +113,7 @@ int flate_hip_set_stream(flate_hip_ctx *ctx, void *hip_stream);
  *   "inflate_spec"       the third decoder -- one wavefront per stream, 64 sub-blocks of the bit
  *                        stream decoded at once from guessed token starts, repeated until the
  *                        starts agree: 0 = never, 1 = for batches below
- *                        "inflate_spec_max_streams" streams (default 36864), 2 = always
+ *                        "inflate_spec_max_streams" streams (default 45056), 2 = always
  *   "inflate_spec_shape" which build of it: 0 (default) = by batch size, 1 = the small-batch one
  *                        (long token lists, 16 KiB history ring), 2 = the large-batch one
  *   "inflate_lanes"      streams per wavefront of that decoder: 0 = chosen from the batch size

@@ -67,10 +67,11 @@ struct flate_hip_ctx {
   // inflate_spec_max streams (where it beats both other decoders), 2 = always (tests)
   int inflate_spec = 1;
   int inflate_spec_shape = 0;  // 0 = by batch size, 1 / 2 = always the small-batch / large-batch build (tests, tuning)
-  uint32_t inflate_spec_max = 36864;  // measured (tools/inflate_crossover.py, ms per batch of 64 KiB text streams):
-                                      // 1024 streams 1.7 against 13.7 (wave per stream) and 27 (lane per
-                                      // stream); 4096: 3.6 / 52 / 25; 16384: 13.8 / - / 29.1; 32768: 27.1 / - / 30.6;
-                                      // 40960: 33.8 / - / 31.9 -- the lane-per-stream decoder wins from ~37 k streams on
+  uint32_t inflate_spec_max = 45056;  // measured (tools/inflate_crossover.py, ms per batch of 64 KiB text streams,
+                                      // sub-block decoder against lane per stream; profiles/r04/inflate_crossover.txt):
+                                      // 8192: 6.7 / 29.3; 16384: 13.1 / 30.8; 32768: 26.0 / 32.4; 40960: 32.4 / 33.7;
+                                      // 49152: 38.8 / 35.3; 65536: 51.6 / 39.3 -- the lane-per-stream decoder wins
+                                      // from ~44 k streams on (round 3, with four of its wavefronts per CU: ~37 k)
   uint32_t resident_blocks = 1024;  // persistent LDS-table blocks (4 per CU x 256 CUs)
   // Entropy stage overlapped with the match finder: the batch is cut into overlap_sub sub-batches
   // (queue order); hist/code/scan/pack of a sub-batch run on ent_stream as soon as the match finder
@@ -1748,9 +1749,10 @@ static int inflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
       else
         hipLaunchKernelGGL(inflate_spec_kernel<FLATE_SPEC_LARGE>, dim3(n), dim3(64), 0, c->stream, I);
     } else if (simt) {
-      // streams per wavefront: as many as still leave four wavefronts (one per SIMD) per CU
+      // streams per wavefront
       int lpw = c->inflate_lanes;
-      if (lpw == 0) lpw = n >= 256u * c->num_cus ? 64 : (n >= 128u * c->num_cus ? 32 : 16);
+      // (measured, same file: 16 lanes per wavefront up to ~20 k streams, 32 up to ~36 k, 64 beyond)
+      if (lpw == 0) lpw = n >= 144u * c->num_cus ? 64 : (n >= 80u * c->num_cus ? 32 : 16);
       const uint32_t sblocks = (n + (uint32_t)lpw - 1) / (uint32_t)lpw;
       // A CU holds eight of these wavefronts (320 B of LDS per lane): a batch of more blocks than
       // that runs in ROUNDS, and a lane's rate depends little on how full the chip is -- so the rounds

@@ -897,7 +897,7 @@ extern __shared__ uint16_t simt_lds[];  // kLaneWords * LPW entries
 
 }  // namespace
 
-// LPW = streams (active lanes) per wavefront; four 64-lane wavefronts fit the LDS of a CU, and a
+// LPW = streams (active lanes) per wavefront; eight 64-lane wavefronts fit the LDS of a CU, and a
 // batch too small to give every SIMD one of those runs with 32 or 16 lanes per wavefront.
 template <int LPW>
 __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
