@@ -22,5 +22,8 @@ tools/traffic_collect.sh ${tag}_c2 16384 65536 > gpurun_out/$tag/traffic_c2.json
 tools/traffic_collect.sh ${tag}_c3 4096 262144 "--option window_units=0" > gpurun_out/$tag/traffic_c3.json 2> gpurun_out/$tag/traffic_c3.err
 tools/inflate_traffic.sh ${tag}_inf > gpurun_out/$tag/traffic_inflate.json 2> gpurun_out/$tag/traffic_inflate.err
 tools/inflate_traffic.sh ${tag}_inf16k 16384 > gpurun_out/$tag/traffic_inflate_16k.json 2> gpurun_out/$tag/traffic_inflate_16k.err
-timeout -k 10 400 python3 tools/inflate_crossover.py 256 1024 4096 8192 16384 32768 65536 > gpurun_out/$tag/inflate_crossover.txt 2>&1 || true
+# (the crossover sweep takes minutes of its own: FLATE_COLLECT_CROSSOVER=1, or run tools/inflate_crossover.py in a call of its own)
+if [ -n "$FLATE_COLLECT_CROSSOVER" ]; then
+  timeout -k 10 400 python3 tools/inflate_crossover.py 256 1024 4096 8192 16384 32768 65536 > gpurun_out/$tag/inflate_crossover.txt 2>&1 || true
+fi
 echo collected
