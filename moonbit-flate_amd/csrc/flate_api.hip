@@ -55,7 +55,6 @@ struct flate_hip_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int guest_blocks = 0;      // 0 = guest kernel off
   uint32_t guest_min = 1280; // below this many streams (5 per CU) the guests stay idle: one block per stream
-  int guest_early = 1;       // guests gather the next batch's table slots a batch early (lz77_stream: EARLY)
   int32_t h_status_word = 0;  // landing pads of small async D2H copies
   uint64_t h_total_bytes = 0;
   uint32_t num_cus = 256;
@@ -347,7 +346,6 @@ int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, cons
   P.done = overlap_sub ? (uint32_t *)c->d_done.p : nullptr;
   P.done_cap = overlap_sub ? kDoneCounters : 0u;
   P.done_split = overlap_sub ? done_split : 0u;
-  P.early = c->guest_early ? 1u : 0u;
   P.gtable_blocks = 0;
   P.spin_limit = c->spin_limit;
   P.inject_drop_push = c->inject_drop_push;
@@ -626,8 +624,6 @@ int flate_hip_set_option(flate_hip_ctx *c, const char *name, int64_t value) {
   const std::string k(name);
   if (k == "guest_blocks" && value >= 0 && value <= 65536) {
     c->guest_blocks = (int)value;
-  } else if (k == "guest_early_gather" && (value == 0 || value == 1)) {
-    c->guest_early = (int)value;
   } else if (k == "guest_min_streams" && value >= 0) {
     c->guest_min = (uint32_t)value;
   } else if (k == "inflate_lanes" && (value == 0 || value == 16 || value == 32 || value == 64)) {
@@ -1124,7 +1120,6 @@ int host_pipe_streams(flate_hip_ctx *c) {
 static void lane_options(flate_hip_ctx *dst, const flate_hip_ctx *src) {
   dst->guest_blocks = src->guest_blocks;
   dst->guest_min = src->guest_min;
-  dst->guest_early = src->guest_early;
   dst->resident_blocks = src->resident_blocks;
   dst->window_units = src->window_units;
   dst->entropy_per_block = src->entropy_per_block;

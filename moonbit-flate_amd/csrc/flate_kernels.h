@@ -42,7 +42,6 @@ struct LzParams {
   uint32_t *done;
   uint32_t done_shift;
   uint32_t done_cap;       // counters behind `done` (an index beyond them sets kStatusBadIndex)
-  uint32_t early;          // guest blocks of single-window launches gather the next batch's slots a batch early
   uint32_t done_split;     // != 0: two sub-batches of unequal size instead: queue entries below it count in
                            // done[0], the others in done[1] (the tail overlap: option overlap_tail_streams)
   uint32_t gtable_blocks;  // tables behind `gtables` (a guest block beyond them does nothing)

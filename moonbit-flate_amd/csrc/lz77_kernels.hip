@@ -194,26 +194,11 @@ FLATE_D void tag_set(uint32_t *tags, uint32_t h, uint32_t t) {
   atomicOr(&tags[h >> 4], t << sh);
 }
 
-// dirty (guest blocks of single-window launches, else null): 2048 bits of LDS for the EARLY table gather.
-// A guest's table gather is a round trip to L2 / the Infinity Cache on every batch's critical path
-// (~ 940 of its ~ 5500 ticks per batch, profiles/r04/README.md).  The slots of the NEXT batch's
-// positions are therefore gathered one batch early: a dense batch at base B also loads the four bytes
-// at B + 64 .. B + 127, hashes them and issues their table gather behind its own candidate gather; the
-// next batch (base B' = B + d, 1 <= d <= 64) takes the slot values of its positions below B + 64 from
-// this batch's registers and the others from that early gather (two ds_bpermute), and goes straight
-// to its candidate gather.  What this batch's commit changes in between is known exactly: a position of
-// this batch keeps the slot value it saw unless an inserted lane shares its slot (eq & INS: then the
-// last of those is what the table holds now); an early lane is affected iff an inserted lane has its
-// slot -- the inserted lanes set a bit per slot (mod 2048) in `dirty`, an early lane whose bit is set
-// looks its slot up among the inserted lanes with one ballot (a false alarm finds none), the bitmap is
-// cleared by one store per lane.  Exact: the value a lane ends up with is the value a fresh gather
-// would return, whatever the races between the early gather and the commit's stores.
 template <bool MULTI, bool GUEST = false>
 FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table, const int lane,
                          const uint32_t c_begin = 0, const uint32_t c_end = 0xffffffffu,
-                         uint32_t *sweep_io = nullptr, uint32_t *tags = nullptr, uint32_t *dirty = nullptr) {
+                         uint32_t *sweep_io = nullptr, uint32_t *tags = nullptr) {
   using E = uint16_t;
-  constexpr bool EARLY = GUEST && !MULTI;
   if (tags && c_begin == 0)
     for (int i = lane; i < kTableSize / 16; i += 64) tags[i] = 0;
   if (c_begin == 0) {
@@ -274,15 +259,6 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
     bool done = false;
     uint4 own_pre = make_uint4(0, 0, 0, 0);  // input bytes of the next dense batch, loaded early
     bool pre_valid = false;
-    // EARLY: what one dense batch leaves for the next (see above)
-    uint32_t e_old = 0;       // slot values of positions p_B + 64 + lane, gathered a batch early (0: none / tag mismatch)
-    uint32_t p_fix = 0;       // slot value of position p_B + lane as the table holds it after that batch's commit
-    uint32_t p_h = 0;         // that batch's slots
-    uint64_t p_INS = 0;       // ... and inserted lanes
-    int p_B = 0;
-    bool e_valid = false;     // e_old / p_fix describe the batch in front of this one
-    uint32_t nb4 = 0;         // the four bytes at (next base) + 64 + lane
-    bool nb_valid = false;
 #ifdef FLATE_LZ_STAMPS
     uint64_t st_load = 0, st_dup = 0, st_ev = 0, st_commit = 0, st_sparse = 0, st_nb = 0, st_ext = 0;
 #endif
@@ -313,46 +289,11 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
         uint32_t h = 0, old = 0;
         bool maybe = false;  // my slot may hold a position with my four bytes
         pf_sink ^= pf_val;  // retire the previous batch's look-ahead load
-        const int ed = B - p_B;
-        const bool use_early = EARLY && INTERIOR && dirty != nullptr &&
-                               __builtin_amdgcn_readfirstlane((int)(e_valid && ed >= 1 && ed <= 64)) != 0;
         if (e1) {
           own = pre_valid ? own_pre : ld128(src + q);
           h = hash4(own.x);
-        }
-#ifdef FLATE_LZ_EARLY_STATS
-        if (use_early) st_ext += 1;              // (diagnostic: batches served by the early gather ...
-        if (EARLY && ed > 64) st_sparse += 1;    //  ... and batches that started too far ahead for it)
-#endif
-        if (use_early) {
-          // my position is lane + ed of the batch in front: its own lane if that is below 64, else its early lane
-          const int sl = lane + ed;
-          const uint32_t fromp = (uint32_t)__shfl((int)p_fix, sl & 63);
-          const uint32_t frome = (uint32_t)__shfl((int)e_old, sl & 63);
-          const bool early_lane = sl >= 64;
-          old = early_lane ? frome : fromp;
-          const uint32_t dw = dirty[(h >> 5) & 63u];
-          uint64_t DL = __ballot(early_lane && ((dw >> (h & 31u)) & 1u) != 0);
-          while (DL) {  // (rare: an inserted lane of that batch may have taken this lane's slot)
-            const int x = __builtin_ctzll(DL);
-            const uint32_t hx = rdlane(h, x);
-            const uint64_t mm = __ballot(p_h == hx) & p_INS;
-            if (mm != 0 && lane == x) old = (W + (uint32_t)p_B + (uint32_t)(63 - __builtin_clzll(mm)) + 1u) & 0xffffu;
-            DL &= DL - 1;
-          }
-          maybe = true;  // (a lane without a candidate has old == 0)
-#ifdef FLATE_LZ_EARLY_CHECK
-          // verification build: the assembled value against a fresh gather, on every lane of every batch
-          if (tag_get(tags, h) == tag_of(own.x) && (uint32_t)table[h] != old) atomicExch(P.status, kStatusBadIndex);
-#endif
-        } else if (e1) {
           maybe = !tags || tag_get(tags, h) == tag_of(own.x);
           if (maybe) old = table[h];
-        }
-        if (EARLY && dirty) {
-          asm volatile("" ::: "memory");
-          dirty[lane] = 0;  // (behind the reads above: the LDS executes a wavefront's instructions in order)
-          asm volatile("" ::: "memory");
         }
         pre_valid = false;
         // candidate = absolute position stored in my slot; valid if within 32768 (:195)
@@ -366,15 +307,6 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
           int pq = B + 768 + 4 * lane;
           if (pq > n - 4) pq = n - 4;
           pf_val = ld32(src + pq);
-        }
-        // EARLY: the table gather of the next batch's positions, behind the candidate gather (loads return
-        // in order: the wait for the candidates does not include it)
-        uint32_t e_new = 0;
-        bool e_next = false;
-        if (EARLY && INTERIOR && dirty != nullptr && __builtin_amdgcn_readfirstlane((int)nb_valid) != 0) {
-          const uint32_t eh = hash4(nb4);
-          if (tag_get(tags, eh) == tag_of(nb4)) e_new = table[eh];
-          e_next = true;
         }
         // DUPall: every lane that shares its slot with another lane of the batch (the commit
         // below must order their writes).  DUP: the lanes whose candidate may be a position
@@ -508,9 +440,7 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
           a = a_s;
           MF |= MFl;
           STAMP(tc1);
-#ifndef FLATE_LZ_EARLY_STATS
           STAMP_ADD(st_sparse, tc1, tc0);
-#endif
           VISall |= VIS;
           s = B + a + 1;
           if (!(x & (1u << 16))) {  // stopped after a fast event
@@ -601,9 +531,7 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
           }
           s = pf + total;
           STAMP(tg1);
-#ifndef FLATE_LZ_EARLY_STATS
           STAMP_ADD(st_ext, tg1, tg0);
-#endif
           if (s >= s_limit) {
             done = true;
             break;
@@ -620,10 +548,6 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
           const int qn = s - 1 + lane;
           if (qn + 1 <= s_limit) own_pre = ld128(src + qn);
           pre_valid = true;
-          if (EARLY && dirty) {  // the bytes the next batch hashes for ITS early gather
-            nb_valid = s - 1 + 64 + 63 + 4 <= n;
-            if (nb_valid) nb4 = ld32(src + qn + 64);
-          }
         }
         // match records of this batch, in position order, one coalesced store
         if ((MF >> lane) & 1) acc_len += (uint32_t)tot_self;
@@ -645,16 +569,6 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
           if (e1 && ((INS >> lane) & 1) && (eq & INS & ~lanes_upto(lane)) == 0) {
             table[h] = (E)A1;
             if (tags) tag_set(tags, h, tag_of(own.x));
-            if (EARLY && dirty) atomicOr(&dirty[(h >> 5) & 63u], 1u << (h & 31u));
-          }
-          if (EARLY && dirty) {  // what the next batch may take from this one
-            const uint64_t mi = eq & INS;
-            p_fix = mi ? ((W + (uint32_t)B + (uint32_t)(63 - __builtin_clzll(mi)) + 1u) & 0xffffu) : old;
-            p_h = h;
-            p_INS = INS;
-            p_B = B;
-            e_old = e_new;
-            e_valid = e_next;
           }
         } else {
           if (e1 && (((DUPall | ~INS) >> lane) & 1)) table[h] = (E)old;
@@ -682,8 +596,6 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
           dense_batch(std::false_type{});
       } else {
         // =============================== sparse batch ==============================
-        e_valid = false;   // (EARLY: a sparse batch inserts without leaving its record ...
-        nb_valid = false;  // ... and the dense batch behind it starts somewhere else)
         const int e = e_idx + lane;
         int p, step;
         if (e < kScanClosedForm) {
@@ -1064,9 +976,7 @@ __global__ __launch_bounds__(64) void lz77_guest_kernel(LzParams P) {
   // units hand a stream from block to block and the tags did not travel; round 3 rebuilds them at the
   // start of a unit instead, see uq_run)
   __shared__ uint32_t tag_mem[kTableSize / 16];  // 4 KiB: see tag_of
-  __shared__ uint32_t dirty_mem[64];             // 256 B: see lz77_stream (EARLY)
   uint32_t *tags = tag_mem;
-  uint32_t *dirty = P.early ? dirty_mem : nullptr;
   if (MULTI && P.uq_ready) {  // persistent, one window at a time, table in place (see uq_run)
     uint32_t push_word = 0;
     for (;;) {
@@ -1089,7 +999,7 @@ __global__ __launch_bounds__(64) void lz77_guest_kernel(LzParams P) {
     q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
     if (q >= P.queue_end) break;
     __syncthreads();
-    lz77_stream<MULTI, true>(P, P.stream_ids[q], table, lane, 0, 0xffffffffu, nullptr, tags, dirty);
+    lz77_stream<MULTI, true>(P, P.stream_ids[q], table, lane, 0, 0xffffffffu, nullptr, tags);
     __syncthreads();
     all_lanes_here(P, lane);
     prev = q;
