@@ -59,10 +59,12 @@ typedef struct flate_hip_ctx flate_hip_ctx;
                                       reference's own (MoonBit) behaviour                */
 #define FLATE_HIP_LZ_SERIAL 0x4u   /* debug: single-lane match finder kernel            */
 #define FLATE_HIP_SIZE_ONLY 0x8u   /* flate_hip_inflate_batch: decode without storing -- out may be
-                                      NULL and out_off is ignored (no capacity limit); out_len[i] =
-                                      the bytes stream i inflates to (up to its error, if any),
-                                      status / err_off as in a real pass.  What a Reader of a
-                                      stream of unknown size runs first, instead of guessing a
+                                      NULL and out_off is ignored; out_len[i] = the bytes stream i
+                                      inflates to (up to its error, if any), status / err_off as in
+                                      a real pass.  The kernels count output in 32 bits: a stream
+                                      that inflates to 4 GiB or more gets FLATE_HIP_E_TOO_LARGE
+                                      (decode it with flate_hip_inflate_stream_read).  What a batch
+                                      caller that needs sizes runs first, instead of guessing a
                                       capacity and retrying                                    */
 
 /* -- lifecycle ------------------------------------------------------------------
@@ -285,6 +287,12 @@ int flate_hip_deflate_fast_spliced(flate_hip_ctx *ctx, const uint8_t *in,
  * A flate_hip_comm wraps one RCCL communicator (created here from a unique id that rank 0
  * makes and the host distributes -- or an existing ncclComm_t) together with the exchange's
  * own HIP stream and the sticky plan {pad, largest stream count} all ranks agree on. */
+/* Verification status: with ONE rank the calls below run over RCCL on the GPU; with TWO ranks their
+ * control flow (peer sizes, rank_base placement, the grouped send / receive loop, refusals and plan
+ * overflows decided alike on every rank) has run over the tests' rehearsal transport -- two processes
+ * on one card, host shared memory in place of RCCL (tests/test_gather_abi.py).  Over RCCL itself
+ * more than one rank has not run yet: the build boxes have one GPU (a test gated on two devices is in
+ * the suite). */
 typedef struct flate_hip_comm flate_hip_comm;
 #define FLATE_HIP_UNIQUE_ID_BYTES 128
 #define FLATE_HIP_GATHER_ALLGATHER 0u /* payloads padded to `pad`, one ncclAllGather; rank r at out + r*pad */

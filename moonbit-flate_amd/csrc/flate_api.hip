@@ -1788,6 +1788,11 @@ static int inflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
   ctl_finish(c);
   const bool used[FLATE_HIP_STAGE_COUNT] = {false, false, false, true};
   if ((rc = collect_timing(c, used))) return rc;
+  // A size-only pass has no capacity -- but the kernels count output in 32 bits: a stream that inflates
+  // to 4 GiB or more stops there with "slot too small", which for a call without slots means "too large"
+  if (size_only)
+    for (uint32_t i = 0; i < n; ++i)
+      if (status[i] == FLATE_HIP_E_OUT_TOO_SMALL) status[i] = FLATE_HIP_E_TOO_LARGE;
   for (uint32_t i = 0; i < n; ++i)
     if (status[i]) return status[i];
   return FLATE_HIP_OK;

@@ -171,3 +171,19 @@ def test_two_ranks_through_the_c_abi_exchange_on_one_card():
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "native gather ok: 2 ranks" in out.stdout
+
+
+@pytest.mark.gpu
+def test_two_ranks_over_rccl_when_the_box_has_two_gpus():
+    """The same script over RCCL itself, one GPU per rank (skipped on the one-GPU boxes of this pool)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "FLATE_HIP_TEST_TRANSPORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "native_gather_ranks.py"), "2"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "native gather ok: 2 ranks" in out.stdout
