@@ -166,3 +166,34 @@ def test_batch_refuses_a_stream_that_reaches_buffer_reset(eng):
     with pytest.raises(flate.FlateError) as ei:
         eng.deflate_batch(np.zeros(16, np.uint8), off, out_cap=64)
     assert ei.value.code == -6
+
+
+def test_the_real_buffer_reset_is_crossed_as_the_reference_crosses_it(oracle):
+    # No lowered threshold here: 32 767 windows + a tail = 2.147 GB through ONE stream, so that `cur`
+    # really reaches buffer_reset = 2^31 - 1 - 131070 at window 32 766 (deflate-fast.mbt:55,130-132) and
+    # shift_offsets clears the table (MoonBit: `prev` is empty).  The data is mostly zeros with a marker
+    # every 4 KiB (one wavefront compresses it at ~60 MB/s and the oracle at ~1 GB/s); the last windows
+    # carry text so that a window that keeps its history and one that lost it differ in many places.
+    n = 32767 * W + 1000
+    data = np.zeros(n, dtype=np.uint8)
+    data[::4096] = (np.arange(data[::4096].size) * 37 + 11).astype(np.uint8)
+    tail_text = flate.synth("text", 1, 6 * W, first_stream=99)
+    data[n - tail_text.size:] = tail_text
+    data[n - 2 * W: n - W] = data[n - 3 * W: n - 2 * W]  # window 32 766 repeats window 32 765: matches across the border
+    want = oracle.deflate(data)
+    try:  # (the shift is visible in this stream: an encoder that never reaches buffer_reset writes other bytes)
+        oracle.set_buffer_reset(0x7fffffff)
+        assert oracle.deflate(data) != want
+    finally:
+        oracle.set_buffer_reset(0)
+    e = flate.FlateEngine(0)
+    try:
+        pieces = [4096] * 7 + [4095]
+        got, _ = _pieces(e, data, pieces)
+        assert len(got) == len(want) and got == want
+        # the same stream without the clear (Go semantics) is a different stream: the shift was visible
+        got_go, _ = _pieces(e, data[n - 3 * W - 1000:], [1, 1], compat_go=True)  # (a fresh stream of the last windows: history kept)
+        assert got_go == oracle.deflate(data[n - 3 * W - 1000:], compat=oracle.COMPAT_GO)
+    finally:
+        e.close()
+    del data
