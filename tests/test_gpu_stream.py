@@ -191,6 +191,22 @@ def test_the_real_buffer_reset_is_crossed_as_the_reference_crosses_it(oracle):
         pieces = [4096] * 7 + [4095]
         got, _ = _pieces(e, data, pieces)
         assert len(got) == len(want) and got == want
+        # and back through the piecewise decoder (64-bit totals, the window across 34 pieces of 64 MiB)
+        r = e.open_inflate_stream()
+        comp = np.frombuffer(got, dtype=np.uint8)
+        pos = at = 0
+        rc = 0
+        for _ in range(10000):
+            take = max(0, (1 << 20) - r.pending_input)
+            chunk = comp[pos:pos + take]
+            pos += chunk.size
+            o, rc = r.feed(chunk, final=pos >= comp.size, room=64 << 20)
+            assert np.array_equal(o, data[at:at + o.size]), at
+            at += o.size
+            if rc != 0:
+                break
+        r.free()
+        assert rc == 1 and at == n and r.total_in == comp.size
         # the same stream without the clear (Go semantics) is a different stream: the shift was visible
         got_go, _ = _pieces(e, data[n - 3 * W - 1000:], [1, 1], compat_go=True)  # (a fresh stream of the last windows: history kept)
         assert got_go == oracle.deflate(data[n - 3 * W - 1000:], compat=oracle.COMPAT_GO)
