@@ -165,8 +165,29 @@ def cpu_leg(host, in_off, n, blen, sample_streams, g_out=None, g_off=None):
         pyoracle.deflate_batch(host[:ns * blen], in_off[:ns + 1], nthreads=nall)
         d = time.perf_counter() - t1
         cdta = d if cdta is None else min(cdta, d)
+    # SURVEY 8(d) context line: libz deflate level 1, raw, the same threads and sample.  A DIFFERENT
+    # algorithm (zlib's deflate_fast with a hash chain, not the reference's) -- context, not parity.
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+
+    def zl(r):
+        tot = 0
+        for i in r:
+            co = zlib.compressobj(1, zlib.DEFLATED, -15)
+            tot += len(co.compress(host[int(in_off[i]):int(in_off[i + 1])])) + len(co.flush())
+        return tot
+    nz = max(1, min(ns, (256 << 20) // max(blen, 1)))
+    t1 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        zbytes = sum(ex.map(zl, [range(k, nz, cores) for k in range(cores)]))
+    zdt = time.perf_counter() - t1
     base = {
         "value": round(ns * blen / cdt / 2**30, 4), "unit": "GiB/s", "cores": cores, "kind": "port",
+        "libz_level1_context": {"value": round(nz * blen / zdt / 2**30, 4), "unit": "GiB/s", "threads": cores,
+                                "ratio": round(nz * blen / max(zbytes, 1), 3),
+                                "note": "zlib %s deflate level 1, raw: a different algorithm, not a parity target"
+                                        % zlib.ZLIB_RUNTIME_VERSION,
+                                "sample": "first %d streams (%d MiB), %.2f s wall" % (nz, nz * blen >> 20, zdt)},
         "sample": "first %d of %d streams (%d MiB), oracle C restatement, %d threads, %.1f s wall"
                   % (ns, n, ns * blen >> 20, cores, cdt),
         "single_thread": {"value": round(n1 * blen / cdt1 / 2**30, 4), "unit": "GiB/s",
