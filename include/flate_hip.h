@@ -246,6 +246,14 @@ int flate_hip_inflate_stream_open(flate_hip_ctx *ctx, flate_hip_inflate_stream *
 int flate_hip_inflate_stream_read(flate_hip_inflate_stream *stream, const uint8_t *in, uint64_t in_len,
                                   int final_in, uint8_t *out, uint64_t out_cap, uint64_t *in_used,
                                   uint64_t *out_len, int64_t *err_off);
+/* Decompressor::reset(r, dict) (inflate.mbt:862-884) and &Reader::new_dict(r, dict) (:315-317): the handle
+ * becomes a fresh decoder (open = reset without a dictionary), optionally with a PRESET DICTIONARY: the
+ * stream decodes as if its output started with `dict`, which has already been read -- the last 32768
+ * bytes of it are kept as history (DictDecoder::new, dict-decoder.mbt:40-60), a distance may reach
+ * min(32768, dict_len + bytes produced) back (:63-69, inflate.mbt:677-680).  dict is a HOST buffer, not
+ * retained; dict_len = 0: none.  (The encoder side, Writer::new_dict, is outside this path: in the
+ * reference it compresses the dictionary into the output as data) */
+int flate_hip_inflate_stream_reset(flate_hip_inflate_stream *stream, const uint8_t *dict, uint64_t dict_len);
 void flate_hip_inflate_stream_free(flate_hip_inflate_stream *stream);
 
 /* The same for the n_streams pieces of ONE spliced stream in[0, in_len) (as written by

@@ -1564,7 +1564,8 @@ int flate_hip_inflate_stream_open(flate_hip_ctx *c, flate_hip_inflate_stream **o
   st->ctx = c;
   int rc = ensure(c, st->state, inflate_stream_state_bytes() + 64);
   if (rc == FLATE_HIP_OK) {
-    hipLaunchKernelGGL(inflate_stream_init_kernel, dim3(1), dim3(64), 0, c->stream, st->state.p);
+    hipLaunchKernelGGL(inflate_stream_init_kernel, dim3(1), dim3(64), 0, c->stream, st->state.p,
+                       (const uint8_t *)nullptr, 0u);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) rc = FLATE_HIP_E_HIP;
   }
   if (rc != FLATE_HIP_OK) {
@@ -1573,6 +1574,32 @@ int flate_hip_inflate_stream_open(flate_hip_ctx *c, flate_hip_inflate_stream **o
     return rc;
   }
   *out = st;
+  return FLATE_HIP_OK;
+}
+
+// Decompressor::reset(r, dict) (inflate.mbt:862-884) / &Reader::new_dict (:315-317): a fresh decoder on
+// the same handle, with the last 32768 bytes of `dict` as history that has already been read
+// (DictDecoder::new, dict-decoder.mbt:40-60).
+int flate_hip_inflate_stream_reset(flate_hip_inflate_stream *st, const uint8_t *dict, uint64_t dict_len) {
+  if (!st || (dict_len && !dict)) return FLATE_HIP_E_INVALID;
+  flate_hip_ctx *c = st->ctx;
+  c->hip_err.clear();
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (dict_len > (uint64_t)kMaxMatchOffset) {
+    dict += dict_len - (uint64_t)kMaxMatchOffset;
+    dict_len = (uint64_t)kMaxMatchOffset;
+  }
+  int rc;
+  if ((rc = ensure(c, st->in, dict_len + 16))) return rc;
+  if (dict_len) HIP_TRY(c, hipMemcpyAsync(st->in.p, dict, dict_len, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(inflate_stream_init_kernel, dim3(1), dim3(256), 0, c->stream, st->state.p,
+                     (const uint8_t *)st->in.p, (uint32_t)dict_len);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  st->status = 0;
+  st->err_off = -1;
+  st->bit_in_byte = 0;
+  st->total_in = st->total_out = 0;
   return FLATE_HIP_OK;
 }
 

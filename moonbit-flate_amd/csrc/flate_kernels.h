@@ -180,7 +180,7 @@ struct InfStreamResult {
   uint32_t in_used, out_len, bit_in_byte;
 };
 size_t inflate_stream_state_bytes();
-__global__ void inflate_stream_init_kernel(void *state);
+__global__ void inflate_stream_init_kernel(void *state, const uint8_t *dict, uint32_t dict_len);
 __global__ void inflate_stream_kernel(void *state, const uint8_t *in, uint32_t in_len, uint32_t final_in,
                                       uint8_t *out, uint32_t out_cap);
 

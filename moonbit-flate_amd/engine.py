@@ -251,9 +251,10 @@ class FlateEngine:
             self._check(rc)
         return out_len[:n], status[:n], err_off[:n]
 
-    def open_inflate_stream(self):
-        """One long DEFLATE stream decoded in pieces (see StreamReader)."""
-        return StreamReader(self)
+    def open_inflate_stream(self, zdict=None):
+        """One long DEFLATE stream decoded in pieces (see StreamReader); zdict: a preset dictionary
+        (&Reader::new_dict, inflate.mbt:315-317)."""
+        return StreamReader(self, zdict)
 
     def open_stream(self, compat_go=False):
         """One stream written in pieces (flate_hip_stream_*): see StreamWriter."""
@@ -401,11 +402,23 @@ class StreamReader:
     on the device in between.  `feed(piece, final, room)` returns (out bytes, status): status 0 = go on,
     1 = end of stream, < 0 = the stream's error (err_off holds corrupt_input_error's offset)."""
 
-    def __init__(self, eng):
+    def __init__(self, eng, zdict=None):
         self._eng, self._L = eng, eng._L
         self._st = C.c_void_p()
         eng._check(self._L.flate_hip_inflate_stream_open(eng._ctx, C.byref(self._st)))
         self._rest = np.zeros(0, dtype=np.uint8)  # bytes a call reported as unused
+        self.err_off = -1
+        self.total_in = 0
+        if zdict is not None and len(zdict):
+            self.reset(zdict)
+
+    def reset(self, zdict=None):
+        """Decompressor::reset(r, dict) (inflate.mbt:862-884): a fresh decoder on the same handle, with the
+        last 32768 bytes of zdict as history that has already been read."""
+        d = np.ascontiguousarray(np.frombuffer(bytes(zdict), dtype=np.uint8) if zdict is not None and not isinstance(zdict, np.ndarray)
+                                 else (zdict if zdict is not None else np.zeros(0, np.uint8)), dtype=np.uint8)
+        self._eng._check(self._L.flate_hip_inflate_stream_reset(self._st, d.ctypes.data if d.size else None, d.size))
+        self._rest = np.zeros(0, dtype=np.uint8)
         self.err_off = -1
         self.total_in = 0
 

@@ -364,17 +364,24 @@ class Reader {
       : r_(&r), e_(e), in_piece_(in_piece < 4096 ? 4096 : in_piece), out_piece_(out_piece < 1 ? 1 : out_piece) {
     (void)size_hint;
   }
+  // &Reader::new_dict(r, dict) (inflate.mbt:315-317): the stream decodes as if its output started with
+  // `dict`, which has already been read (its last 32768 bytes are the history, dict-decoder.mbt:40-60)
+  static std::unique_ptr<Reader> new_dict(ByteSource &r, Engine &e, std::vector<uint8_t> dict, size_t in_piece = 1u << 20,
+                                          size_t out_piece = 1u << 20) {
+    std::unique_ptr<Reader> rd(new Reader(r, e, 0, in_piece, out_piece));
+    rd->dict_ = std::move(dict);
+    return rd;
+  }
   ~Reader() { flate_hip_inflate_stream_free(st_); }
   Reader(const Reader &) = delete;
   Reader &operator=(const Reader &) = delete;
 
-  // Decompressor::reset (inflate.mbt:862-884; without a preset dictionary, which is outside the
-  // scope table): forget everything and decode the stream `r` delivers next.
-  void reset(ByteSource &r, uint64_t size_hint = 0) {
-    (void)size_hint;
+  // Decompressor::reset(r, dict) (inflate.mbt:862-884): forget everything and decode the stream `r`
+  // delivers next, with `dict` (may be empty) as its preset dictionary.
+  void reset(ByteSource &r, std::vector<uint8_t> dict = {}) {
     r_ = &r;
-    flate_hip_inflate_stream_free(st_);
-    st_ = nullptr;
+    dict_ = std::move(dict);
+    fresh_ = true;  // (the handle, if any, is reset in front of the next decode)
     in_.clear();
     src_end_ = false;
     data_.clear();
@@ -415,6 +422,15 @@ class Reader {
         err_ = make_error(e_, rc);
         return;
       }
+      fresh_ = !dict_.empty();
+    }
+    if (fresh_) {
+      const int rc = flate_hip_inflate_stream_reset(st_, dict_.data(), dict_.size());
+      if (rc != 0) {
+        err_ = make_error(e_, rc);
+        return;
+      }
+      fresh_ = false;
     }
     while (!src_end_ && in_.size() < in_piece_) {
       const size_t at = in_.size();
@@ -448,6 +464,8 @@ class Reader {
   Engine &e_;
   size_t in_piece_, out_piece_;
   flate_hip_inflate_stream *st_ = nullptr;
+  std::vector<uint8_t> dict_;  // preset dictionary of the stream being decoded (kept for nothing else)
+  bool fresh_ = false;         // the handle must be reset before it decodes
   std::vector<uint8_t> in_;   // the bytes of the stream the decoder has not used yet
   bool src_end_ = false;
   std::vector<uint8_t> data_;  // decoded, not handed out yet (to_read, inflate.mbt:286)

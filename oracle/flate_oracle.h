@@ -122,6 +122,10 @@ size_t orc_deflate_bound(size_t n);
  * bytes read (roffset), *err_off = offset reported by corrupt_input_error. */
 int orc_inflate_stream(const uint8_t *in, size_t n, uint8_t *out, size_t cap,
                        size_t *out_len, size_t *consumed, long long *err_off);
+/* &Reader::new_dict (inflate.mbt:315-317): the same with a preset dictionary, whose last 32768 bytes
+ * are history that has already been read (DictDecoder::new, dict-decoder.mbt:40-60). */
+int orc_inflate_stream_dict(const uint8_t *in, size_t n, const uint8_t *dict, size_t dict_len, uint8_t *out,
+                            size_t cap, size_t *out_len, size_t *consumed, long long *err_off);
 /* The same for n independent streams over nthreads host threads; stream i is
  * in[in_off[i]..in_off[i+1]) -> out[out_off[i]..out_off[i+1]) (capacity).  Returns the first
  * non-zero status. */

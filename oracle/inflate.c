@@ -118,6 +118,11 @@ typedef struct {
   int codebits[NUM_CODES];
   uint8_t *out;
   size_t out_len, out_cap;
+  /* preset dictionary (&Reader::new_dict, inflate.mbt:315-317; Decompressor::reset :862-884):
+   * DictDecoder::new (dict-decoder.mbt:40-60) keeps its last HIST_SIZE bytes as history that
+   * "has already been read": the output behaves as if it started with them. */
+  const uint8_t *dict;
+  size_t dict_len; /* <= HIST_SIZE */
   int final_flag;
   int err;
   long long err_off;
@@ -340,13 +345,19 @@ static int huffman_block(decompressor *f, const huffman_decoder *hl,
       return corrupt(f);
     }
 
-    size_t hist = f->out_len < HIST_SIZE ? f->out_len : HIST_SIZE;
+    /* hist_size (dict-decoder.mbt:63-69): the window is full, or wr_pos = dictionary + output */
+    size_t hist = f->out_len + f->dict_len < HIST_SIZE ? f->out_len + f->dict_len : HIST_SIZE;
     if ((size_t)dist > hist) return corrupt(f); /* :677-680 */
 
     if (f->out_len + (size_t)length > f->out_cap) return f->err = ORC_E_OUT_TOO_SMALL;
     uint8_t *dst = f->out + f->out_len;
-    const uint8_t *src = dst - dist;
-    for (int i = 0; i < length; i++) dst[i] = src[i]; /* forward (overlapping) copy */
+    if ((size_t)dist <= f->out_len) {
+      const uint8_t *src = dst - dist;
+      for (int i = 0; i < length; i++) dst[i] = src[i]; /* forward (overlapping) copy */
+    } else { /* the copy starts inside the preset dictionary and may run on into the output */
+      long long p = (long long)f->out_len - dist; /* < 0: dictionary byte dict_len + p */
+      for (int i = 0; i < length; i++, p++) dst[i] = p < 0 ? f->dict[(long long)f->dict_len + p] : f->out[p];
+    }
     f->out_len += (size_t)length;
   }
 }
@@ -395,8 +406,19 @@ static const huffman_decoder *get_fixed(void) {
 /* inflate.mbt:345-379 (next_block) driven until final_flag (finish_block :769) */
 int orc_inflate_stream(const uint8_t *in, size_t n, uint8_t *out, size_t cap,
                        size_t *out_len, size_t *consumed, long long *err_off) {
+  return orc_inflate_stream_dict(in, n, NULL, 0, out, cap, out_len, consumed, err_off);
+}
+
+int orc_inflate_stream_dict(const uint8_t *in, size_t n, const uint8_t *dict, size_t dict_len, uint8_t *out,
+                            size_t cap, size_t *out_len, size_t *consumed, long long *err_off) {
   static __thread decompressor fs;
   decompressor *f = &fs;
+  if (dict_len > HIST_SIZE) { /* dict-decoder.mbt:48-50: only the last `size` bytes are kept */
+    dict += dict_len - HIST_SIZE;
+    dict_len = HIST_SIZE;
+  }
+  f->dict = dict;
+  f->dict_len = dict_len;
   f->in = in;
   f->in_len = n;
   f->roffset = 0;

@@ -26,8 +26,8 @@ MAX_STORE_BLOCK_SIZE = 65535
 
 def build(force=False):
     """Compile the oracle with gcc (Makefile in this directory)."""
-    if force or not os.path.exists(_LIB_PATH):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "libflate_oracle.so"])
+    # (always through make: it rebuilds only when a source is newer than the library)
+    subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []) + ["libflate_oracle.so"])
     return _LIB_PATH
 
 
@@ -53,6 +53,10 @@ def lib():
                                          C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
                                          C.POINTER(C.c_longlong)]
         L.orc_inflate_stream.restype = C.c_int
+        L.orc_inflate_stream_dict.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                              C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
+                                              C.POINTER(C.c_longlong)]
+        L.orc_inflate_stream_dict.restype = C.c_int
         L.orc_deflate_bound.argtypes = [C.c_size_t]
         L.orc_deflate_bound.restype = C.c_size_t
         L.orc_df_new.argtypes = [C.c_int]
@@ -127,14 +131,17 @@ def deflate(data, writes=None, compat=COMPAT_MOONBIT, with_blocks=False):
     return res
 
 
-def inflate(data, max_out, full=False):
-    """&Reader::new(buf) read to EOF -> bytes (raises on error unless full)."""
+def inflate(data, max_out, full=False, zdict=None):
+    """&Reader::new(buf) -- or &Reader::new_dict(buf, zdict) -- read to EOF -> bytes (raises on error
+    unless full)."""
     L = lib()
     src = _as_u8(data)
     out = np.empty(max(max_out, 1), dtype=np.uint8)
     out_len, consumed, err_off = C.c_size_t(0), C.c_size_t(0), C.c_longlong(-1)
-    rc = L.orc_inflate_stream(src.ctypes.data, src.size, out.ctypes.data, max_out,
-                              C.byref(out_len), C.byref(consumed), C.byref(err_off))
+    d = _as_u8(zdict) if zdict is not None and len(zdict) else None
+    rc = L.orc_inflate_stream_dict(src.ctypes.data, src.size, d.ctypes.data if d is not None else None,
+                                   d.size if d is not None else 0, out.ctypes.data, max_out,
+                                   C.byref(out_len), C.byref(consumed), C.byref(err_off))
     res = out[:out_len.value].tobytes()
     if full:
         return rc, res, consumed.value, err_off.value

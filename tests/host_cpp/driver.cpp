@@ -12,7 +12,20 @@ static void hex(const char *tag, const std::vector<uint8_t> &b) {
   printf("\n");
 }
 
-int main() {
+static std::vector<uint8_t> read_all(Reader &r, Err &last) {
+  std::vector<uint8_t> got, piece(5000);
+  for (int k = 0; k < 100000; ++k) {
+    auto rr = r.read(piece.data(), piece.size());
+    got.insert(got.end(), piece.begin(), piece.begin() + rr.first);
+    if (rr.second) {
+      last = rr.second;
+      break;
+    }
+  }
+  return got;
+}
+
+int main(int argc, char **argv) {
   Engine eng(0);
   if (!eng.ok()) {
     printf("noengine %d\n", eng.status());
@@ -207,6 +220,38 @@ int main() {
     }
     printf("long_reader %s %zu %s %zu %d\n", ce ? ce->msg.c_str() : "none", total, last ? last->msg.c_str() : "none", diff,
            most <= 65536 + 100000 + 8192 ? 1 : 0);
+  }
+  // &Reader::new_dict / Decompressor::reset(r, dict) (inflate.mbt:315-317,862-884).  argv[1]: a file
+  // the test wrote -- u32 dictionary length, dictionary, u32 stream length, a stream compressed against it
+  if (argc > 1) {
+    FILE *f = fopen(argv[1], "rb");
+    uint32_t dl = 0, cl = 0;
+    std::vector<uint8_t> dict, comp;
+    if (f && fread(&dl, 4, 1, f) == 1) {
+      dict.resize(dl);
+      if (dl && fread(dict.data(), 1, dl, f) != dl) dict.clear();
+      if (fread(&cl, 4, 1, f) == 1) {
+        comp.resize(cl);
+        if (cl && fread(comp.data(), 1, cl, f) != cl) comp.clear();
+      }
+    }
+    if (f) fclose(f);
+    BytesReader src(comp);
+    auto r = Reader::new_dict(src, eng, dict, 4096, 7000);
+    Err last;
+    std::vector<uint8_t> got = read_all(*r, last);
+    printf("dict_read %zu %s\n", got.size(), last ? last->msg.c_str() : "none");
+    hex("dict_plain", got);
+    BytesReader src2(comp);  // the same handle without the dictionary: the first far copy is corrupt
+    r->reset(src2);
+    Err last2;
+    std::vector<uint8_t> got2 = read_all(*r, last2);
+    printf("nodict_read %zu %s\n", got2.size(), last2 ? last2->msg.c_str() : "none");
+    BytesReader src3(comp);  // and with it again
+    r->reset(src3, dict);
+    Err last3;
+    std::vector<uint8_t> got3 = read_all(*r, last3);
+    printf("redict_read %zu %s %d\n", got3.size(), last3 ? last3->msg.c_str() : "none", got3 == got ? 1 : 0);
   }
   return 0;
 }

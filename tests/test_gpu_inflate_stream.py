@@ -19,10 +19,10 @@ def eng():
     e.close()
 
 
-def drive(eng, comp, in_piece, out_room, rng=None, max_calls=200000):
+def drive(eng, comp, in_piece, out_room, rng=None, max_calls=200000, zdict=None, reader=None):
     """Feed `comp` in pieces of in_piece bytes (or random sizes up to it), take out_room bytes at a time.
     Returns (out bytes, final status, err_off, input bytes consumed, calls)."""
-    r = eng.open_inflate_stream()
+    r = reader if reader is not None else eng.open_inflate_stream(zdict)
     comp = np.frombuffer(bytes(comp), dtype=np.uint8)
     pos, out, calls = 0, [], 0
     try:
@@ -44,7 +44,8 @@ def drive(eng, comp, in_piece, out_room, rng=None, max_calls=200000):
                 # the decoder wants more although nothing is left: cannot happen with final set
                 raise AssertionError("stalled at the end of the input")
     finally:
-        r.free()
+        if reader is None:
+            r.free()
 
 
 KINDS = [("text", 200000), ("zero", 300000), ("rand", 70000), ("low", 100000), ("runs", 150000), ("period", 180000),
@@ -147,3 +148,74 @@ def test_sticky_status_and_argument_rules(eng, oracle):
     o, rc = r.feed(b"", final=True)
     assert rc == -7                       # an empty stream is an unexpected EOF (inflate.mbt:345-349)
     r.free()
+
+
+# ---- preset dictionary: &Reader::new_dict / Decompressor::reset(r, dict) (inflate.mbt:315-317,862-884) ----
+def zdeflate(data, zdict, level=6):
+    co = zlib.compressobj(level, zlib.DEFLATED, -15, 9, zlib.Z_DEFAULT_STRATEGY, zdict)
+    return co.compress(data) + co.flush()
+
+
+@pytest.mark.parametrize("dlen", [1, 258, 4096, 32767, 32768, 32769, 50000])
+def test_preset_dictionary(eng, oracle, dlen):
+    zdict = flate.synth("text", 1, dlen, seed=11).tobytes()
+    data = zdict[-min(dlen, 3000):] + flate.synth("text", 1, 90000, seed=12).tobytes() + zdict[:min(dlen, 5000)]
+    comp = zdeflate(data, zdict)
+    rc0, want, used0, _ = oracle.inflate(comp, len(data) + 8, full=True, zdict=zdict)
+    assert rc0 == 0 and want == data
+    for in_piece, room in ((1 << 20, 1 << 20), (4096, 10000), (700, 333), (1500, 1 << 16)):
+        got, rc, _, used, _ = drive(eng, comp, in_piece, room, zdict=zdict)
+        assert rc == 1 and got == data and used == len(comp), (dlen, in_piece, room, rc, len(got))
+    got, rc, _, used, _ = drive(eng, comp, 3000, 5000, rng=np.random.default_rng(dlen), zdict=zdict)
+    assert rc == 1 and got == data and used == len(comp)
+
+
+def test_dictionary_too_short_or_missing_is_the_oracles_corrupt(eng, oracle):
+    zdict = flate.synth("text", 1, 8192, seed=21).tobytes()
+    data = zdict[1000:1400] + b"tail" + zdict[3000:3300] + flate.synth("text", 1, 40000, seed=22).tobytes()
+    comp = zdeflate(data, zdict)
+    for d in (None, zdict[-1000:], zdict[-5000:], b"x" * 5000 + zdict, zdict):
+        rc0, out0, used0, eo0 = oracle.inflate(comp, len(data) + 8, full=True, zdict=d)
+        want_rc = {0: 1, oracle.E_CORRUPT: -4}[rc0]
+        for in_piece, room in ((1 << 16, 1 << 16), (700, 100), (1 << 16, 3)):
+            got, rc, eo, used, _ = drive(eng, comp, in_piece, room, zdict=d)
+            assert (rc, got) == (want_rc, out0), (None if d is None else len(d), in_piece, room, rc, len(got), len(out0))
+            if rc0:
+                assert eo == eo0 and used == used0
+
+
+def test_copy_from_the_dictionary_running_into_the_output(eng, oracle):
+    zdict = b"....abcdeZ"
+    data = b"xyz" + b"Zxyz" * 4000
+    comp = zdeflate(data, zdict, 9)
+    assert oracle.inflate(comp, len(data), zdict=zdict) == data
+    for in_piece, room in ((1 << 16, 1 << 16), (640, 5), (1000, 1)):
+        got, rc, _, _, _ = drive(eng, comp, in_piece, room, zdict=zdict)
+        assert rc == 1 and got == data
+
+
+def test_reset_reuses_the_handle_with_and_without_a_dictionary(eng, oracle):
+    zdict = flate.synth("text", 1, 20000, seed=31).tobytes()
+    a = zdict[5000:9000] + flate.synth("text", 1, 50000, seed=32).tobytes()
+    ca, cb = zdeflate(a, zdict), oracle.deflate(np.frombuffer(a, np.uint8))
+    r = eng.open_inflate_stream()
+    try:
+        for rounds in range(2):
+            r.reset(zdict)
+            got, rc, _, _, _ = drive(eng, ca, 2000, 3000, reader=r)
+            assert rc == 1 and got == a
+            r.reset()  # Decompressor::reset(r, []) -- the dictionary is gone
+            got, rc, _, _, _ = drive(eng, cb, 2000, 3000, reader=r)
+            assert rc == 1 and got == a
+            r.reset()  # a stream that needs the dictionary fails without it, and the error is not kept
+            got, rc, _, _, _ = drive(eng, ca, 2000, 3000, reader=r)
+            assert rc == -4
+        # reset in the middle of a stream: the half-decoded state is dropped
+        r.reset(zdict)
+        o, rc = r.feed(np.frombuffer(ca[:1000], np.uint8), final=False, room=500)
+        assert rc == 0 and o.size > 0
+        r.reset(zdict)
+        got, rc, _, _, _ = drive(eng, ca, 1 << 16, 1 << 16, reader=r)
+        assert rc == 1 and got == a
+    finally:
+        r.free()

@@ -31,7 +31,18 @@ def test_host_mirror_compiles_without_gpu():
 @pytest.mark.gpu
 def test_host_mirror_matches_reference_behaviour(oracle):
     exe = _compile()
-    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    import struct
+    import tempfile
+    import zlib
+    zdict = flate.synth("text", 1, 40000, seed=41).tobytes()
+    dict_plain = zdict[30000:33000] + flate.synth("text", 1, 30000, seed=42).tobytes()
+    co = zlib.compressobj(6, zlib.DEFLATED, -15, 9, zlib.Z_DEFAULT_STRATEGY, zdict)
+    dict_comp = co.compress(dict_plain) + co.flush()
+    case = tempfile.NamedTemporaryFile(suffix=".bin", delete=False)
+    case.write(struct.pack("<I", len(zdict)) + zdict + struct.pack("<I", len(dict_comp)) + dict_comp)
+    case.close()
+    out = subprocess.run([exe, case.name], capture_output=True, text=True, timeout=120)
+    os.unlink(case.name)
     assert out.returncode == 0, out.stdout + out.stderr
     lines = dict()
     streams, reads = [], []
@@ -104,3 +115,10 @@ def test_host_mirror_matches_reference_behaviour(oracle):
     # 6 MB through a Reader with a 64 KiB input piece and a 100 000-byte output piece: all bytes, ioeof
     # with the last ones, and never more resident than the two pieces
     assert lines["long_reader"] == "none 6000000 EOF 0 1"
+    # &Reader::new_dict, then the same handle reset without and with the dictionary (inflate.mbt:315,862)
+    assert lines["dict_read"] == "%d EOF" % len(dict_plain)
+    assert bytes.fromhex(lines["dict_plain"]) == dict_plain
+    rc, part, _, eoff = oracle.inflate(dict_comp, len(dict_plain) + 8, full=True)
+    assert rc == oracle.E_CORRUPT
+    assert lines["nodict_read"] == "%d flate: corrupt input before offset %d" % (len(part), eoff)
+    assert lines["redict_read"] == "%d EOF 1" % len(dict_plain)
