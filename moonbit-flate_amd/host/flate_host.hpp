@@ -117,6 +117,21 @@ class Writer {
   // emit_windows: full windows staged before they are compressed and handed to the sink (16 = 1 MiB)
   Writer(ByteSink &w, Engine &e, uint32_t flags = 0, size_t chunk_bytes = 0, size_t emit_windows = 16)
       : w_(w), e_(e), flags_(flags), chunk_(chunk_bytes), emit_(emit_windows ? emit_windows : 1) {}
+  // Writer::new_dict(w, dict) (writer.mbt:25-31) AS THE REFERENCE BEHAVES: fill_window
+  // (deflate.mbt:108-151) copies the last window_size = 32768 bytes of the dictionary into the input
+  // window and sets window_end, i.e. they are unprocessed DATA -- the stream is the one Writer::new
+  // produces when those bytes are written first (the reference's own test asserts exactly that
+  // equality, deflate_test.mbt:12-35).  Go ignores the dictionary at this level.
+  static std::unique_ptr<Writer> new_dict(ByteSink &w, Engine &e, const uint8_t *dict, size_t n, uint32_t flags = 0) {
+    std::unique_ptr<Writer> wr(new Writer(w, e, flags));
+    constexpr size_t kDictWindow = 32768;  // window_size, deflate.mbt:12
+    if (n > kDictWindow) {
+      dict += n - kDictWindow;
+      n = kDictWindow;
+    }
+    wr->pending_.assign(dict, dict + n);
+    return wr;
+  }
   ~Writer() { flate_hip_stream_free(st_); }
   Writer(const Writer &) = delete;
   Writer &operator=(const Writer &) = delete;

@@ -45,6 +45,15 @@ int main(int argc, char **argv) {
   printf("close2 %s\n", e2 ? e2->msg.c_str() : "none");
   auto r3 = w.write((const uint8_t *)d1, 3);  // deflate.mbt:281-283
   printf("write_after_close %d %s\n", r3.first, r3.second ? r3.second->msg.c_str() : "none");
+  // deflate_test.mbt:25-35: new_dict("hello world") + write("hello again world") + close gives the SAME bytes
+  {
+    Buffer b1;
+    auto wd = Writer::new_dict(b1, eng, (const uint8_t *)d1, strlen(d1));
+    auto rd = wd->write((const uint8_t *)d2, strlen(d2));
+    Err ed = wd->close();
+    printf("dictwrite %d %s %d\n", rd.first, ed ? ed->msg.c_str() : "none", b1.bytes == b.bytes ? 1 : 0);
+    hex("dicthello", b1.bytes);
+  }
   // a batch: empty stream, 65536-byte ramp, 100 zero bytes
   std::vector<std::vector<uint8_t>> in(3), out;
   in[1].resize(65536);
