@@ -404,6 +404,17 @@ class Reader {
     err_ = std::nullopt;
   }
 
+  // Decompressor::make_reader (inflate.mbt:857-860): the stream goes on from another source; nothing
+  // else changes (bytes already pulled from the old source are used first).
+  void make_reader(ByteSource &r) {
+    r_ = &r;
+    src_end_ = false;
+  }
+  // The reference pulls its source a byte at a time and stops at the end of the final block; this
+  // Reader pulls a piece ahead.  What it pulled and did not use -- the bytes BEHIND the stream when the
+  // source holds more than one payload -- is here (valid once read() has returned the stream's end).
+  const std::vector<uint8_t> &unread() const { return in_; }
+
   std::pair<int, Err> read(uint8_t *p, size_t n) {
     for (;;) {
       if (pos_ < data_.size()) {  // :384-396

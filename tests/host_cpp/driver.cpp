@@ -87,6 +87,20 @@ int main(int argc, char **argv) {
     for (int k = 0; k < r2.first; ++k) nz += big[k] != 0;
     printf("reset %d %s %zu\n", r2.first, r2.second ? r2.second->msg.c_str() : "none", nz);
   }
+  // a source that holds more than the stream: the reader stops at the end of the final block, what it
+  // pulled ahead is handed back; and make_reader (inflate.mbt:857-860) before the first read
+  {
+    std::vector<uint8_t> two = b.bytes;
+    const char *behind = "NEXT PAYLOAD";
+    two.insert(two.end(), behind, behind + strlen(behind));
+    BytesReader other(std::vector<uint8_t>{0x07}), src(two);
+    Reader r(other, eng);
+    r.make_reader(src);
+    Err last;
+    std::vector<uint8_t> got = read_all(r, last);
+    printf("trailing %zu %s %.*s\n", got.size(), last ? last->msg.c_str() : "none", (int)r.unread().size(),
+           (const char *)r.unread().data());
+  }
   // a corrupt stream: reserved block type in the first header (bits 1,1,1)
   {
     std::vector<uint8_t> bad = b.bytes;

@@ -281,3 +281,59 @@ def test_lane_per_stream_decoder_in_several_rounds(oracle):
         assert bytes(out[:int(ooff[-1])]) == want
     finally:
         e.close()
+
+
+def test_literal_only_blocks_errors_and_long_codes(eng, oracle):
+    """Blocks without length codes (the encoder's Huffman-only blocks; zlib's Z_HUFFMAN_ONLY) take their own
+    path in the sub-block decoder (pointer jumping over the code lengths): random bytes with 7/8/9-bit
+    codes, skewed alphabets whose rare bytes have codes longer than the 9-bit table, a one-symbol
+    alphabet (1-bit codes: the shortest window), several blocks per stream, and corruptions, truncated
+    inputs and output slots that end anywhere -- statuses, error offsets and bytes are the oracle's."""
+    rng = np.random.default_rng(404)
+
+    def huff_only(raw, level=6):
+        co = zlib.compressobj(level, zlib.DEFLATED, -15, 9, zlib.Z_HUFFMAN_ONLY)
+        return co.compress(raw) + co.flush()
+
+    raws = [bytes(rng.integers(0, 256, 70000, dtype=np.uint8)),
+            bytes(rng.integers(0, 256, 200000, dtype=np.uint8)),                      # several blocks
+            bytes(np.minimum(rng.geometric(0.08, 90000) - 1, 255).astype(np.uint8)),  # codes of 2 .. 15 bits
+            bytes(np.minimum(rng.geometric(0.5, 50000) - 1, 255).astype(np.uint8)),
+            b"a" * 30000, bytes(rng.integers(0, 2, 40000, dtype=np.uint8)),
+            bytes(rng.integers(0, 256, 100, dtype=np.uint8)), bytes(rng.integers(0, 256, 17, dtype=np.uint8))]
+    blobs, caps = [], []
+    for raw in raws:
+        for good in (huff_only(raw), oracle.deflate(np.frombuffer(raw, np.uint8))):
+            blobs.append(good)
+            caps.append(len(raw))
+            blobs.append(good)
+            caps.append(len(raw) + 77)
+            for _ in range(3):  # a flipped byte
+                g = bytearray(good)
+                k = int(rng.integers(0, len(g)))
+                g[k] ^= int(rng.integers(1, 256))
+                blobs.append(bytes(g))
+                caps.append(len(raw) + 1000)
+            for _ in range(2):  # truncated input, output slot too small
+                blobs.append(good[:int(rng.integers(1, len(good)))])
+                caps.append(len(raw) + 1000)
+                blobs.append(good)
+                caps.append(int(rng.integers(0, len(raw))))
+    data, off = _pack(blobs)
+    out, ooff, olen, status, err = eng.inflate_batch(data, off, caps, check=False)
+    for i, bl in enumerate(blobs):
+        rc, res, used, eoff = oracle.inflate(bl, caps[i], full=True)
+        want_status = {0: 0, oracle.E_CORRUPT: -4, oracle.E_UNEXPECTED_EOF: -7, oracle.E_OUT_TOO_SMALL: -2}[rc]
+        assert int(status[i]) == want_status, (i, int(status[i]), rc)
+        assert int(err[i]) == eoff, (i, int(err[i]), eoff)
+        if rc == 0:
+            assert bytes(out[int(ooff[i]):int(ooff[i]) + int(olen[i])]) == res
+    # sizes without output (FLATE_HIP_SIZE_ONLY) take the same path
+    good = [b for b, c in zip(blobs, caps)][0::10]
+    d2, o2 = _pack(good)
+    olen2, st2, _ = eng.inflate_sizes(d2, o2)
+    for i, bl in enumerate(good):
+        rc, res, _, _ = oracle.inflate(bl, 1 << 20, full=True)
+        assert (int(st2[i]) == 0) == (rc == 0)
+        if rc == 0:
+            assert int(olen2[i]) == len(res)

@@ -59,6 +59,7 @@ def test_host_mirror_matches_reference_behaviour(oracle):
     want = oracle.deflate(b"hello world" + b"hello again world")
     assert len(want) == 38 and bytes.fromhex(lines["hello"]) == want   # deflate_test.mbt:23
     assert lines["dictwrite"] == "17 none 1" and bytes.fromhex(lines["dicthello"]) == want  # deflate_test.mbt:25-35
+    assert lines["trailing"] == "28 EOF NEXT PAYLOAD"                   # make_reader :857-860; read-ahead handed back
     assert lines["close2"] == "none"                                    # deflate.mbt:158-160
     assert lines["write_after_close"] == "0 writer closed"              # deflate.mbt:281-283
     assert lines["batch"] == "none"
