@@ -99,14 +99,6 @@ int flate_hip_set_stream(flate_hip_ctx *ctx, void *hip_stream);
  *                        lanes (sub-contexts with their own HIP streams and scratch, one host thread
  *                        each), so that the match finder of group g+1 fills the chip while group g's
  *                        last streams, entropy kernels and size read-back drain; 1: one lane
- *   "overlap_sub_batches"  > 0: the entropy kernels of every sub-batch (queue order) run on a
- *                        second HIP stream as soon as the match finder has counted its streams
- *                        done (default 0: measured slower on MI355X)
- *   "overlap_tail_streams"  k > 0: the uneven form of the same overlap -- the entropy kernels of all but
- *                        the last k streams start while the persistent match-finder launch drains its
- *                        last streams (every block publishes its finished streams once, when it is first
- *                        handed a queue entry behind the split); single-window batches only (default 0:
- *                        measured equal at best on MI355X, profiles/r04/README.md)
  *   "entropy_per_block"  -1 (default): the histogram and pack kernels run one wavefront per BLOCK
  *                        instead of per stream when the batch's streams have three or more blocks
  *                        on average; 0 = never; 1 = whenever every stream has a block
@@ -121,7 +113,7 @@ int flate_hip_set_stream(flate_hip_ctx *ctx, void *hip_stream);
  *   "inflate_lanes"      streams per wavefront of that decoder: 0 = chosen from the batch size
  *                        (default), or 16 / 32 / 64
  *   "spin_limit_polls"   the persistent kernels' waits (a window that another block is still
- *                        producing, the gate of an overlapped sub-batch) give up after this many
+ *                        producing) give up after this many
  *                        polls and the call returns FLATE_HIP_E_INTERNAL (default 8 Mi polls,
  *                        several seconds of a running wave; time spent preempted does not count)
  *   "stream_rebase_bytes"  flate_hip_stream_*: a stream longer than this moves the origin of the

@@ -11,9 +11,8 @@ __global__ __launch_bounds__(1024) void scan_sizes_kernel(CompactParams P) {
   __shared__ uint64_t wtot[16];
   __shared__ uint64_t carry_s;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const uint32_t lo = P.carry ? P.first : 0u;
-  const uint32_t hi = P.carry ? P.first + P.count : P.n_streams;
-  if (tid == 0) carry_s = P.carry ? *P.carry : 0ull;
+  const uint32_t lo = 0u, hi = P.n_streams;
+  if (tid == 0) carry_s = 0ull;
   __syncthreads();
   for (uint32_t base = lo; base < hi; base += 1024) {
     const uint32_t i = base + (uint32_t)tid;
@@ -34,28 +33,9 @@ __global__ __launch_bounds__(1024) void scan_sizes_kernel(CompactParams P) {
     __syncthreads();
   }
   if (tid == 0) {
-    if (P.carry) *P.carry = carry_s;
-    if (hi == P.n_streams) P.out_off[P.n_streams] = carry_s;
+    P.out_off[P.n_streams] = carry_s;
     if (carry_s > P.out_cap) *P.status = -2;  // FLATE_HIP_E_OUT_TOO_SMALL
   }
-}
-
-// Gate of a sub-batch of the entropy stage: the match finder (still running on other HIP streams)
-// counts the streams of the sub-batch it has finished; this one-lane kernel returns when all of
-// them are there.  The spin is bounded by a number of polls (spin_limit; a wave that is not
-// running -- preempted, time-sliced with another process -- does not count against it): a count
-// that never arrives becomes an error code (kStatusGateTimeout), not a hang.
-__global__ void wait_count_kernel(const uint32_t *counter, uint32_t target, int *status, uint32_t spin_limit) {
-  for (uint32_t polls = 0;; ++polls) {
-    const uint32_t v = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (v >= target) break;
-    if (polls >= spin_limit) {
-      atomicExch(status, kStatusGateTimeout);
-      break;
-    }
-    __builtin_amdgcn_s_sleep(32);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
 // The small index arrays of a call (stream offsets in, sizes and statuses out) travel by THIS kernel,

@@ -73,27 +73,13 @@ struct flate_hip_ctx {
                                       // 49152: 38.8 / 35.3; 65536: 51.6 / 39.3 -- the lane-per-stream decoder wins
                                       // from ~44 k streams on (round 3, with four of its wavefronts per CU: ~37 k)
   uint32_t resident_blocks = 1024;  // persistent LDS-table blocks (4 per CU x 256 CUs)
-  // Entropy stage overlapped with the match finder: the batch is cut into overlap_sub sub-batches
-  // (queue order); hist/code/scan/pack of a sub-batch run on ent_stream as soon as the match finder
-  // -- one launch over the whole batch -- has counted all of its streams done.  0 = off (default:
-  // measured slower on MI355X, profiles/r02/README.md -- the entropy kernels run 3x slower beside
-  // the match finder than after it, so nothing is gained).
-  int overlap_sub = 0;
-  // The UNEVEN form: two sub-batches, the last overlap_tail queue entries and everything in front of
-  // them.  The entropy kernels of the large first part start as soon as its last stream is done and run
-  // while the persistent match-finder launch drains (its blocks run dry over the last ~2.7 ms, one
-  // stream's time); the short second part follows the launch.  0 = off.
-  uint32_t overlap_tail = 0;
-  uint32_t overlap_resident = 1024;  // LDS-table blocks while overlapping (4 per CU: leaves 32 KiB
-                                     // of LDS per CU to the entropy kernels)
-  hipStream_t ent_stream = nullptr;
-  hipEvent_t ev_ent = nullptr, ev_lz = nullptr;  // (ev_lz: the match finder's launches have finished)
-  std::vector<hipEvent_t> ent_ev;    // profiling: start/end of every sub-batch's entropy kernels
-  DevBuf d_done;                     // overlap_sub counters + the running output size (u64)
+  // (Rounds 2-4 carried an entropy stage OVERLAPPED with the match finder -- sub-batches gated on counters
+  // the persistent launch incremented, in an even and an uneven form.  Never faster than running the two one
+  // after the other (profiles/r02, r04), and a soak run of round 4 once saw the pack kernel's self-check fire
+  // in the even form, not reproduced in 115 000 stress runs: removed)
   // window-granular scheduling of multi-window streams (lz77_kernels.hip, uq_*): on by default
   int window_units = 1;
   DevBuf d_uq_ready, d_uq_tables, d_uq_sweep;
-  bool overlapped = false;           // what the last encode call did
   // measurement aids (flate_hip_last_resident_share, option "profile_split_streams")
   uint32_t profile_split = 0;        // > 0: LDS-table blocks take exactly the first K queue entries,
                                      // the guest blocks the rest (two queues instead of one)
@@ -105,7 +91,7 @@ struct flate_hip_ctx {
   // out (two copy threads on two non-blocking streams).  0 = one copy in, compress, one copy out.
   int host_groups = 8;
   uint32_t host_group_streams = 2048;  // a group holds at least this many streams (inflate: four times as many)
-  // bounded waits of the persistent kernels (uq_pop, wait_count_kernel): polls before giving up
+  // bounded waits of the persistent kernels (uq_pop): polls before giving up
   // (a poll is one relaxed load + s_sleep, >= 0.4 us; a wave that is not running does not count)
   uint32_t spin_limit = 8u << 20;
   uint32_t inject_drop_push = 0;  // test hook: the k-th window hand-over (1-based) is dropped
@@ -309,10 +295,9 @@ int collect_timing(flate_hip_ctx *c, const bool used[FLATE_HIP_STAGE_COUNT]) {
 }
 
 // Upload the index arrays and run the match finder over every LZ77 chunk.
-// overlap_sub > 0: count finished streams per sub-batch of that many queue entries in c->d_done
 // (the caller has checked that the launch is one persistent resident+guest launch in stream order)
 int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, const StagePlan &pl,
-             uint32_t flags, uint32_t overlap_sub = 0, uint32_t done_split = 0) {
+             uint32_t flags) {
   const uint32_t n = pl.n_streams;
   int rc;
   if ((rc = ensure(c, c->d_in_off, ((size_t)n + 1) * 8))) return rc;
@@ -343,9 +328,6 @@ int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, cons
   P.gtables = nullptr;
   P.queue = nullptr;
   P.queue_end = 0;
-  P.done = overlap_sub ? (uint32_t *)c->d_done.p : nullptr;
-  P.done_cap = overlap_sub ? kDoneCounters : 0u;
-  P.done_split = overlap_sub ? done_split : 0u;
   P.gtable_blocks = 0;
   P.spin_limit = c->spin_limit;
   P.inject_drop_push = c->inject_drop_push;
@@ -380,8 +362,6 @@ int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, cons
       uq_units = 0;
     }
   }
-  P.done_shift = 0;
-  while (overlap_sub && (1u << P.done_shift) < overlap_sub) ++P.done_shift;  // (a power of two)
   if (c->guest_blocks > 0) {
     if ((rc = ensure(c, c->d_gtables, (size_t)c->guest_blocks * kTableSize * 2 + 64))) return rc;
     if ((rc = ensure(c, c->d_queue, 64))) return rc;
@@ -452,7 +432,6 @@ int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, cons
         (void)hipEventRecord(c->ev_fork, c->stream);
         (void)hipStreamWaitEvent(c->guest_stream, c->ev_fork, 0);
         uint32_t resident = c->resident_blocks < count ? c->resident_blocks : count;
-        if (overlap_sub && !done_split && c->overlap_resident < resident) resident = c->overlap_resident;
         if (multi) {
           hipLaunchKernelGGL(lz77_guest_kernel<true>, dim3((uint32_t)c->guest_blocks), dim3(64), 0,
                              c->guest_stream, G);
@@ -536,10 +515,7 @@ int flate_hip_init(int device, flate_hip_ctx **out) {
     return FLATE_HIP_E_NO_DEVICE;
   }
   c->stream = c->own_stream;
-  if (hipStreamCreateWithFlags(&c->ent_stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_ent, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_lz, hipEventDisableTiming) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->guest_stream, hipStreamNonBlocking) != hipSuccess ||
+  if (hipStreamCreateWithFlags(&c->guest_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
     flate_hip_destroy(c);
@@ -556,7 +532,6 @@ int flate_hip_init(int device, flate_hip_ctx **out) {
                                         // persistent; 1280: 3.41 vs 2.35; 2048: 3.61 vs 2.76; 3072: 5.55 vs 3.96
     c->resident_blocks = 4u * (uint32_t)cus;
     c->guest_blocks = 13 * cus / 2;
-    c->overlap_resident = 4u * (uint32_t)cus;
   }
   if (const char *e = getenv("FLATE_HIP_GUEST_BLOCKS")) c->guest_blocks = atoi(e) < 0 ? 0 : atoi(e);
   if (const char *e = getenv("FLATE_HIP_GUEST_MIN")) c->guest_min = (uint32_t)atoi(e);
@@ -598,12 +573,6 @@ void flate_hip_destroy(flate_hip_ctx *c) {
   for (auto &e : c->ev)
     if (e) (void)hipEventDestroy(e);
   if (c->guest_stream) (void)hipStreamDestroy(c->guest_stream);
-  if (c->ent_stream) (void)hipStreamDestroy(c->ent_stream);
-  if (c->ev_ent) (void)hipEventDestroy(c->ev_ent);
-  if (c->ev_lz) (void)hipEventDestroy(c->ev_lz);
-  for (auto &e : c->ent_ev)
-    if (e) (void)hipEventDestroy(e);
-  release(c->d_done);
   release(c->d_uq_ready);
   release(c->d_uq_tables);
   release(c->d_uq_sweep);
@@ -648,12 +617,6 @@ int flate_hip_set_option(flate_hip_ctx *c, const char *name, int64_t value) {
     c->profile_split = (uint32_t)value;
   } else if (k == "window_units" && (value == 0 || value == 1)) {
     c->window_units = (int)value;
-  } else if (k == "overlap_sub_batches" && value >= 0 && value <= 64) {
-    c->overlap_sub = (int)value;
-  } else if (k == "overlap_tail_streams" && value >= 0 && value <= 0x7fffffff) {
-    c->overlap_tail = (uint32_t)value;
-  } else if (k == "overlap_resident_blocks" && value > 0 && value <= 65536) {
-    c->overlap_resident = (uint32_t)value;
   } else if (k == "spin_limit_polls" && value > 0 && value <= 0x7fffffff) {
     c->spin_limit = (uint32_t)value;
   } else if (k == "entropy_per_block" && value >= -1 && value <= 1) {
@@ -786,7 +749,7 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
   // its closing block in that form).  Not for spliced output: where a block starts then depends on
   // the bit its stream starts at (a stored block pads to a byte of the SPLICED stream), which only the
   // stream's own walk knows.
-  bool per_block = c->entropy_per_block != 0 && pl.n_blocks > 0 && c->overlap_sub == 0 && !spliced &&
+  bool per_block = c->entropy_per_block != 0 && pl.n_blocks > 0 && !spliced &&
                    (c->entropy_per_block == 1 || (uint64_t)pl.n_blocks >= 3ull * n);
   for (uint32_t i = 0; i < n && per_block; ++i) per_block = pl.blk_base[i + 1] > pl.blk_base[i];
   std::vector<uint32_t> blk_sid;
@@ -798,48 +761,7 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
     if ((rc = ctl_up(c, c->d_blk_sid.p, blk_sid.data(), (size_t)pl.n_blocks * 4))) return rc;
   }
 
-  // Overlap (see flate_hip_ctx::overlap_sub): possible when the match finder is ONE persistent
-  // resident+guest launch whose queue is the stream order (every stream has LZ77 chunks and all are
-  // of one kind), the output is not spliced (the splice needs every stream's size first) and the
-  // wave kernels run (the single-lane debug kernel does not count its streams).
-  const uint32_t list = (uint32_t)(pl.ids16.size() == n ? n : (pl.ids32.size() == n ? n : 0));
-  // (single-window streams only: window units count their streams elsewhere, uq_pop)
-  const bool tail_form = c->overlap_tail > 0 && c->overlap_sub == 0 && n >= 4u * c->overlap_tail && pl.ids16.size() == n;
-  const bool overlap = (c->overlap_sub > 0 || tail_form) && !spliced && list == n && n >= c->guest_min &&
-                       c->guest_blocks > 0 && !(flags & FLATE_HIP_LZ_SERIAL) &&
-                       (tail_form || n >= 4u * (uint32_t)c->overlap_sub);
-  c->overlapped = overlap;
-  // sub-batch size: the power of two that gives at most overlap_sub sub-batches
-  uint32_t sub = n;
-  if (overlap && !tail_form) {
-    sub = 1;
-    while ((uint64_t)sub * (uint32_t)c->overlap_sub < n) sub <<= 1;
-  }
-  // first stream of every sub-batch (and n)
-  std::vector<uint32_t> sb;
-  if (overlap && tail_form) {
-    sb = {0u, n - c->overlap_tail, n};
-  } else {
-    for (uint32_t f = 0; f < n; f += sub) sb.push_back(f);
-    sb.push_back(n);
-  }
-  const uint32_t J = overlap ? (uint32_t)sb.size() - 1u : 1u;
-  if (overlap) {
-    // the counters the match finder increments (P.done + (q >> done_shift), q < n): J of them
-    if (J > kDoneCounters) return FLATE_HIP_E_INTERNAL;
-    if ((rc = ensure(c, c->d_done, kDoneCounters * 4 + 16))) return rc;
-    HIP_TRY(c, hipMemsetAsync(c->d_done.p, 0, kDoneCounters * 4 + 16, c->stream));
-    while (c->ent_ev.size() < 2 * (size_t)J) {
-      hipEvent_t e = nullptr;
-      HIP_TRY(c, hipEventCreate(&e));
-      c->ent_ev.push_back(e);
-    }
-  }
-  if ((rc = run_lz77(c, d_in, in_off, pl, flags, overlap ? sub : 0u, (overlap && tail_form) ? sb[1] : 0u))) return rc;
-  // ev_fork sits on c->stream right in front of the match finder's launch, behind every upload
-  // and memset the entropy kernels depend on
-  if (overlap) (void)hipStreamWaitEvent(c->ent_stream, c->ev_fork, 0);
-  if (overlap && tail_form) (void)hipEventRecord(c->ev_lz, c->stream);  // (behind the join of both launches)
+  if ((rc = run_lz77(c, d_in, in_off, pl, flags))) return rc;
 
   HuffParams H{};
   H.in = d_in;
@@ -863,7 +785,6 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
   H.status = (int *)c->d_status.p;
   H.n_streams = n;
   H.compat_go = (flags & FLATE_HIP_COMPAT_GO) ? 1u : 0u;
-  H.sid0 = 0;
   H.blk_sid = per_block ? (const uint32_t *)c->d_blk_sid.p : nullptr;
   CompactParams C{};
   C.out_len = (const uint64_t *)c->d_out_len.p;
@@ -871,36 +792,7 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
   C.out_cap = out_cap;
   C.n_streams = n;
   C.status = (int *)c->d_status.p;
-  C.first = 0;
-  C.count = n;
-  C.carry = nullptr;
-  if (overlap) {
-    // the sub-batches in queue order on ent_stream, each behind its gate; the match finder keeps
-    // running on c->stream / guest_stream
-    uint32_t *done = (uint32_t *)c->d_done.p;
-    C.carry = (uint64_t *)((uint8_t *)c->d_done.p + kDoneCounters * 4);
-    for (uint32_t j = 0; j < J; ++j) {
-      const uint32_t first = sb[j];
-      const uint32_t cnt = sb[j + 1] - sb[j];
-      if (!cnt) continue;
-      if (tail_form && j == 1)  // the short last part simply follows the launch
-        (void)hipStreamWaitEvent(c->ent_stream, c->ev_lz, 0);
-      else
-        hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(1), 0, c->ent_stream, done + j, cnt,
-                           (int *)c->d_status.p, c->spin_limit);
-      if (c->profiling) (void)hipEventRecord(c->ent_ev[2 * j], c->ent_stream);
-      H.sid0 = first;
-      C.first = first;
-      C.count = cnt;
-      hipLaunchKernelGGL(huff_hist_kernel, dim3(cnt), dim3(64), 0, c->ent_stream, H);
-      hipLaunchKernelGGL(huff_code_kernel, dim3(cnt), dim3(64), 0, c->ent_stream, H);
-      hipLaunchKernelGGL(scan_sizes_kernel, dim3(1), dim3(1024), 0, c->ent_stream, C);
-      hipLaunchKernelGGL(huff_pack_kernel, dim3(cnt), dim3(64), 0, c->ent_stream, H);
-      if (c->profiling) (void)hipEventRecord(c->ent_ev[2 * j + 1], c->ent_stream);
-    }
-    (void)hipEventRecord(c->ev_ent, c->ent_stream);
-    (void)hipStreamWaitEvent(c->stream, c->ev_ent, 0);
-  } else {
+  {
     StageTimer t(c, FLATE_HIP_STAGE_HUFF_PACK);
     if (per_block)
       hipLaunchKernelGGL(huff_hist_block_kernel, dim3(pl.n_blocks), dim3(64), 0, c->stream, H);
@@ -942,13 +834,10 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
       c->hip_err = "a persistent match-finder loop lost lanes of its wavefront (miscompiled loop?)";
       return FLATE_HIP_E_INTERNAL;
     }
-    if (c->h_status_word == kStatusUqTimeout || c->h_status_word == kStatusGateTimeout ||
-        c->h_status_word == kStatusBadIndex) {
+    if (c->h_status_word == kStatusUqTimeout || c->h_status_word == kStatusBadIndex) {
       c->hip_err = c->h_status_word == kStatusUqTimeout
                        ? "a match-finder block waited for a window that was never handed over"
-                       : (c->h_status_word == kStatusGateTimeout
-                              ? "the entropy stage's gate waited for a sub-batch the match finder never finished"
-                              : "a match-finder block was handed an index outside its scratch");
+                       : "a match-finder block was handed an index outside its scratch";
       return FLATE_HIP_E_INTERNAL;
     }
     if (c->h_status_word <= -0x100000) {  // encoder self-check (huff_pack_kernel): -(0x100000 + stream)
@@ -963,23 +852,6 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
   if (!dev) {
     HIP_TRY(c, hipMemcpyAsync(out, c->d_out.p, produced, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-  }
-  if (c->overlapped) {
-    // huff_pack = the time the entropy kernels were busy (sum over the sub-batches, gate waits
-    // excluded); it runs beside lz77_match, so the two no longer add up to the step
-    const bool used[FLATE_HIP_STAGE_COUNT] = {true, false, false, false};
-    if ((rc = collect_timing(c, used))) return rc;
-    if (c->profiling) {
-      float tot = 0.f;
-      for (uint32_t j = 0; j < J; ++j) {
-        if (sb[j + 1] == sb[j]) continue;
-        float ms = 0.f;
-        HIP_TRY(c, hipEventElapsedTime(&ms, c->ent_ev[2 * j], c->ent_ev[2 * j + 1]));
-        tot += ms;
-      }
-      c->stage_ms[FLATE_HIP_STAGE_HUFF_PACK] = tot;
-    }
-    return FLATE_HIP_OK;
   }
   const bool used[FLATE_HIP_STAGE_COUNT] = {true, true, false, false};
   return collect_timing(c, used);
@@ -1123,9 +995,6 @@ static void lane_options(flate_hip_ctx *dst, const flate_hip_ctx *src) {
   dst->resident_blocks = src->resident_blocks;
   dst->window_units = src->window_units;
   dst->entropy_per_block = src->entropy_per_block;
-  dst->overlap_sub = src->overlap_sub;
-  dst->overlap_tail = src->overlap_tail;
-  dst->overlap_resident = src->overlap_resident;
   dst->spin_limit = src->spin_limit;
   dst->profile_split = src->profile_split;
   dst->profiling = src->profiling;

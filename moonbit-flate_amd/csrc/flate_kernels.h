@@ -9,14 +9,12 @@ namespace flate {
 // deflate.mbt:236-277): every full 65535-byte window plus a final partial window
 // of >= 128 bytes.  chunk_base[i] .. chunk_base[i+1] are stream i's chunks; chunk c
 // owns match records [c * kMatchCapPerChunk, (c+1) * kMatchCapPerChunk).
-// counters of the overlapped entropy stage (flate_hip_ctx::d_done): at most this many sub-batches
-constexpr uint32_t kDoneCounters = 64;
 // device-side status words that the host turns into FLATE_HIP_E_INTERNAL with a message
 // (a range of their own: no device-only word may alias a public FLATE_HIP_E_* code, which some status
 // words are -- FLATE_HIP_E_OUT_TOO_SMALL from the scan kernels -- and which a caller may be handed raw;
 // every value <= kStatusUqTimeout is an internal condition, the pack self-check's -(0x100000 + stream) too)
 constexpr int kStatusUqTimeout = -0x1001;    // uq_pop: the unit with my ticket was never pushed
-constexpr int kStatusGateTimeout = -0x1002;  // wait_count_kernel: a sub-batch was never finished
+constexpr int kStatusGateTimeout = -0x1002;  // (retired with the overlapped entropy stage; the number stays reserved)
 constexpr int kStatusBadIndex = -0x1003;     // an index outside the scratch it addresses (never expected)
 constexpr int kStatusLanesLost = -0x1004;    // a persistent loop is running without all 64 lanes
 static_assert(kStatusUqTimeout < -64 && kStatusLanesLost > -0x100000, "device-only status words: their own range");
@@ -37,13 +35,6 @@ struct LzParams {
   void *gtables;        // one table per guest block
   uint32_t *queue;      // next index into stream_ids
   uint32_t queue_end;
-  // overlap with the entropy stage: done[q >> done_shift] counts the finished streams of every
-  // sub-batch of the queue (null = off); incremented after the stream's records are visible
-  uint32_t *done;
-  uint32_t done_shift;
-  uint32_t done_cap;       // counters behind `done` (an index beyond them sets kStatusBadIndex)
-  uint32_t done_split;     // != 0: two sub-batches of unequal size instead: queue entries below it count in
-                           // done[0], the others in done[1] (the tail overlap: option overlap_tail_streams)
   uint32_t gtable_blocks;  // tables behind `gtables` (a guest block beyond them does nothing)
   uint32_t spin_limit;     // polls before a bounded wait gives up
   uint32_t inject_drop_push;  // test hook (option debug_drop_window_push): drop that hand-over
@@ -92,7 +83,6 @@ struct HuffParams {
   int *status;
   uint32_t n_streams;
   uint32_t compat_go;
-  uint32_t sid0;  // first stream of this launch (sub-batched launches; block b handles sid0 + b)
   const uint32_t *blk_sid;  // per-block launches (huff_*_block_kernel): stream of every block, else null
   uint32_t no_close;  // spliced mode: the batch's last stream does not write Writer::close's block
                       // (a stream that continues in a later call: flate_hip_stream_write)
@@ -104,11 +94,6 @@ struct CompactParams {
   uint64_t out_cap;
   uint32_t n_streams;
   int *status;  // set to FLATE_HIP_E_OUT_TOO_SMALL if the total exceeds out_cap
-  // sub-batched scan: streams [first, first + count) continue from *carry (device; the bytes of
-  // all earlier streams) and leave the new total there; the launch that reaches n_streams also
-  // writes out_off[n_streams] and checks out_cap.  carry == null: one launch over everything.
-  uint32_t first, count;
-  uint64_t *carry;
 };
 
 struct InfParams {
@@ -156,7 +141,6 @@ __global__ void scan_sizes_kernel(CompactParams P);
 __global__ void copy_ctl_kernel(uint32_t *dst, const uint32_t *src, size_t nwords);
 // spins (bounded) until *counter >= target: gates a sub-batch of the entropy stage on the match
 // finder that is still running on another stream
-__global__ void wait_count_kernel(const uint32_t *counter, uint32_t target, int *status, uint32_t spin_limit);
 __global__ void inflate_kernel(InfParams P);
 // one wavefront per stream, 64 sub-blocks of the bit stream decoded at once (inflate_spec_kernel.inc):
 // <bits per sub-block, tokens per list, bytes of history ring>

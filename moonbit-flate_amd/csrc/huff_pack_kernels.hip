@@ -823,7 +823,7 @@ FLATE_D void hist_block(const HuffParams &P, SharedHist &sh, const BlockGeom &g,
 __global__ __launch_bounds__(64) void huff_hist_kernel(HuffParams P) {
   __shared__ SharedHist sh;
   const int lane = threadIdx.x;
-  const uint32_t sid = blockIdx.x + P.sid0;
+  const uint32_t sid = blockIdx.x;
   if (sid >= P.n_streams) return;
   const BlockGeom g = block_geom(P, sid);
   fill_len_code(sh, lane);
@@ -849,7 +849,7 @@ __global__ __launch_bounds__(64) void huff_hist_block_kernel(HuffParams P) {
 __global__ __launch_bounds__(64) void huff_code_kernel(HuffParams P) {
   __shared__ Shared sh;
   const int lane = threadIdx.x;
-  const uint32_t sid = blockIdx.x + P.sid0;
+  const uint32_t sid = blockIdx.x;
   if (sid >= P.n_streams) return;
   const BlockGeom g = block_geom(P, sid);
   uint64_t bitpos = 0;
@@ -1073,7 +1073,7 @@ FLATE_D void pack_block(const HuffParams &P, SharedPack &sh, BitSink &S, const B
 __global__ __launch_bounds__(64) void huff_pack_kernel(HuffParams P) {
   __shared__ SharedPack sh;
   const int lane = threadIdx.x;
-  const uint32_t sid = blockIdx.x + P.sid0;
+  const uint32_t sid = blockIdx.x;
   if (sid >= P.n_streams || *P.status != 0) return;
   const BlockGeom g = block_geom(P, sid);
 

@@ -719,12 +719,6 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
   if (sweep_io) *sweep_io = next_sweep;
 }
 
-// Overlap with the entropy stage (flate_api.hip): queue entry q is finished -- make its match
-// records and counts visible device-wide, then count it in its sub-batch.  Called by ONE lane, from
-// the single lane-0 block of the persistent loops (a second lane-0 block at the end of the loop
-// body next to the one at its start made the compiler peel lane 0 off the loop: see uq_pop); the
-// release covers the whole wavefront's stores: the wait the compiler emits in front of the L2
-// write-back is the wave's vmcnt, and a wave barrier precedes the call.
 // Every lane of the wavefront must still be in the persistent loop.  hipcc once peeled lane 0 off
 // such a loop (see uq_pop): the blocks then ran every later stream with lane 0 masked off and
 // produced wrong records silently.  The code shape that avoids it is kept, and this turns a
@@ -732,31 +726,6 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
 FLATE_D void all_lanes_here(const LzParams &P, int lane) {
   const uint64_t here = __ballot(true);
   if (here != ~0ull && lane == (int)__builtin_ctzll(here)) atomicExch(P.status, kStatusLanesLost);
-}
-
-FLATE_D void stream_done_lane0(const LzParams &P, uint32_t q) {
-  if (!P.done || P.done_split) return;  // (done_split: see tail_done_lane0)
-  const uint32_t k = q >> P.done_shift;
-  if (k < P.done_cap)  // (the host sizes the counters for exactly this; anything else is a bug, not a fault)
-    __hip_atomic_fetch_add(P.done + k, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  else
-    atomicExch(P.status, kStatusBadIndex);
-}
-
-// The UNEVEN form of the overlap (P.done_split != 0: the entropy kernels of queue entries [0, done_split)
-// start while this launch drains its last streams).  A release per finished stream -- the write-back of
-// the XCD's whole L2 -- is what made the even form cost the match finder 0.7 ms; writing the records
-// through L2 instead cost 1.4 ms (measured: every batch's few records then leave as their own partial
-// sector).  A block takes its queue entries in increasing order, so it needs ONE release: when it is
-// first handed an entry at or behind the split (or none at all), every stream it has finished belongs
-// to the first part and nothing it will still finish does.  `pending` lives in lane 0.
-FLATE_D void tail_done_lane0(const LzParams &P, uint32_t prev, uint32_t q_next, uint32_t &pending) {
-  if (!P.done || !P.done_split) return;
-  if (prev != 0xffffffffu && prev < P.done_split) ++pending;
-  if (pending && q_next >= P.done_split) {
-    __hip_atomic_fetch_add(P.done, pending, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    pending = 0;
-  }
 }
 
 // ---------------------------------------------------------------------------------
@@ -787,9 +756,7 @@ FLATE_D UqUnit uq_pop(const LzParams &P, const uint32_t push_word, int lane) {
   // lane 0 off the unit loop: after the first unit the guest blocks ran without it.)
   uint32_t t = 0;
   if (lane == 0) {
-    if (push_word & 0x80000000u) {  // the previous unit was its stream's last window
-      stream_done_lane0(P, push_word & 0x7fffffffu);
-    } else if (push_word != 0) {
+    if (push_word != 0 && !(push_word & 0x80000000u)) {  // (bit 31: the previous unit was its stream's last window)
       const uint32_t k = __hip_atomic_fetch_add(P.uq_ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // (test hook: option debug_drop_window_push loses one hand-over, so that the bounded wait
       // below can be shown to end in an error code and not in a hang)
@@ -936,17 +903,12 @@ __global__ __launch_bounds__(64) void lz77_wave_kernel(LzParams P) {
   }
   // Either one block per stream (P.queue == null) or persistent: resident and guest blocks
   // share one queue (dynamic balance).  One call site keeps a single copy of the parser.
-  uint32_t mine = 0, prev = 0xffffffffu;  // streams taken; the entry finished in the previous round
-  uint32_t pending = 0;                   // (lane 0) finished streams of the first part, not published yet
+  uint32_t mine = 0;  // streams taken
   for (bool first = true;; first = false) {
     uint32_t q;
     if (P.queue) {
       q = 0;
-      if (lane == 0) {  // the ONE lane-0 block of the loop (see stream_done_lane0)
-        if (prev != 0xffffffffu) stream_done_lane0(P, prev);
-        q = atomicAdd(P.queue, 1u);
-        tail_done_lane0(P, prev, q, pending);
-      }
+      if (lane == 0) q = atomicAdd(P.queue, 1u);  // (the ONE lane-0 block of the loop: see uq_pop)
       q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
       if (q >= P.queue_end) break;
     } else {
@@ -957,7 +919,6 @@ __global__ __launch_bounds__(64) void lz77_wave_kernel(LzParams P) {
     lz77_stream<MULTI>(P, P.stream_ids ? P.stream_ids[q] : q, table, lane);
     __syncthreads();
     all_lanes_here(P, lane);
-    prev = q;
     ++mine;
   }
   if (P.taken && lane == 0) __hip_atomic_fetch_add(P.taken, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -987,22 +948,15 @@ __global__ __launch_bounds__(64) void lz77_guest_kernel(LzParams P) {
     }
     return;
   }
-  uint32_t prev = 0xffffffffu;
-  uint32_t pending = 0;  // (lane 0) finished streams of the first part, not published yet
   for (;;) {
     uint32_t q = 0;
-    if (lane == 0) {  // the ONE lane-0 block of the loop (see stream_done_lane0)
-      if (prev != 0xffffffffu) stream_done_lane0(P, prev);
-      q = atomicAdd(P.queue, 1u);
-      tail_done_lane0(P, prev, q, pending);
-    }
+    if (lane == 0) q = atomicAdd(P.queue, 1u);  // (the ONE lane-0 block of the loop: see uq_pop)
     q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
     if (q >= P.queue_end) break;
     __syncthreads();
     lz77_stream<MULTI, true>(P, P.stream_ids[q], table, lane, 0, 0xffffffffu, nullptr, tags);
     __syncthreads();
     all_lanes_here(P, lane);
-    prev = q;
   }
 }
 

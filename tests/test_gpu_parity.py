@@ -232,10 +232,9 @@ def test_full_size_config3_default_geometry(oracle):
         e.close()
 
 
-def test_overlapped_entropy_stage_is_bit_exact(oracle):
-    # option "overlap_sub_batches": hist/code/scan/pack of a sub-batch run on a second HIP stream as
-    # soon as the match finder (one launch over the whole batch) has counted its streams done.
-    # Off by default (measured slower); the results must not depend on it.
+def test_launch_geometry_does_not_change_the_bytes(oracle):
+    # the persistent match finder with few or many LDS-table and guest blocks (every block then takes many
+    # streams from the queue, or hardly any), and multi-window streams with and without window units
     n = 1024
     data = flate.synth("text", n, 65536)
     off = flate.uniform_offsets(n, 65536)
@@ -243,43 +242,27 @@ def test_overlapped_entropy_stage_is_bit_exact(oracle):
     e = flate.FlateEngine(0)
     try:
         e.set_option("guest_min_streams", 1)
-        for sub in (1, 4, 8, 64):
-            e.set_option("overlap_sub_batches", sub)
+        for blocks in ((8, 8), (64, 256), (1024, 1664)):
+            e.set_option("resident_blocks", blocks[0])
+            e.set_option("guest_blocks", blocks[1])
             out, out_off = e.deflate_batch(data, off)
             for i in range(n):
                 a = out[int(out_off[i]):int(out_off[i + 1])]
                 b = want[int(w_off[i]):int(w_off[i]) + int(w_len[i])]
-                assert a.size == b.size and np.array_equal(a, b), (sub, i)
-        # the UNEVEN form ("overlap_tail_streams"): everything but the last k streams is one sub-batch,
-        # gated on a count every block publishes once (when it is first handed an entry behind the split)
-        e.set_option("overlap_sub_batches", 0)
-        for tail in (1, 64, 200, 256):
-            e.set_option("overlap_tail_streams", tail)
-            for blocks in ((8, 8), (64, 256)):
-                e.set_option("resident_blocks", blocks[0])
-                e.set_option("guest_blocks", blocks[1])
-                out, out_off = e.deflate_batch(data, off)
-                for i in range(n):
-                    a = out[int(out_off[i]):int(out_off[i + 1])]
-                    b = want[int(w_off[i]):int(w_off[i]) + int(w_len[i])]
-                    assert a.size == b.size and np.array_equal(a, b), ("tail", tail, blocks, i)
-        e.set_option("overlap_tail_streams", 0)
-        e.set_option("resident_blocks", 1024)
-        e.set_option("guest_blocks", 1664)
-        # multi-window streams: the match finder then hands windows between blocks (window units)
-        # while the entropy stage of finished sub-batches already runs
+                assert a.size == b.size and np.array_equal(a, b), (blocks, i)
+        # multi-window streams: the match finder hands windows between blocks (window units) or keeps a
+        # stream on its block
         n2, blen2 = 192, 150000
         data2 = flate.synth("text", n2, blen2, first_stream=5000)
         off2 = flate.uniform_offsets(n2, blen2)
         want2, w_off2, w_len2 = oracle.deflate_batch(data2, off2, nthreads=8)
-        for sub, units in ((8, 1), (8, 0), (0, 1)):
-            e.set_option("overlap_sub_batches", sub)
+        for units in (1, 0):
             e.set_option("window_units", units)
             out, out_off = e.deflate_batch(data2, off2)
             for i in range(n2):
                 a = out[int(out_off[i]):int(out_off[i + 1])]
                 b = want2[int(w_off2[i]):int(w_off2[i]) + int(w_len2[i])]
-                assert a.size == b.size and np.array_equal(a, b), ("multi", sub, units, i)
+                assert a.size == b.size and np.array_equal(a, b), ("multi", units, i)
     finally:
         e.close()
 

@@ -26,7 +26,7 @@ while time.time() - t0 < budget:
     guests = bool(rng.integers(2))
     eng.set_option("guest_min_streams", 1 if guests else 1 << 30)
     eng.set_option("guest_blocks", int(rng.choice([8, 64, 256])) if guests else 0)
-    eng.set_option("overlap_sub_batches", int(rng.choice([0, 0, 2, 8])))  # (only takes effect on uniform batches)
+    int(rng.choice([0, 0, 2, 8]))  # (a draw that once chose an option since removed: later draws stay what they were)
     eng.set_option("entropy_per_block", int(rng.choice([-1, 0, 1, 1])))   # (1: one wavefront per block where possible)
     cm = O.COMPAT_GO if go else O.COMPAT_MOONBIT
     if rng.random() < 0.3:  # some rounds without empty streams, so that the per-block entropy kernels really run
@@ -55,15 +55,14 @@ while time.time() - t0 < budget:
     eng.set_option("inflate_spec", 1)
     back, _, olen, status, _ = eng.inflate_spliced(np.concatenate([one[:nb], np.zeros(8, np.uint8)]), nb, bit_off, szs)
     assert (status == 0).all() and bytes(back[:int(off[-1])]) == data[:int(off[-1])].tobytes(), "inflate_spliced (%s)" % tag
-    if rounds % 7 == 3:  # a uniform batch: the overlapped entropy stage is eligible
+    if rounds % 7 == 3:  # a uniform batch on a fixed launch geometry (one persistent launch, few blocks per stream)
         eng.set_option("guest_min_streams", 1)
         eng.set_option("guest_blocks", 64)
         un = int(rng.integers(64, 400))
         if rng.random() < 0.5:
-            eng.set_option("overlap_sub_batches", int(rng.choice([1, 4, 8, 16])))
-        else:  # the uneven form: one large first part, gated on the blocks' single counts
-            eng.set_option("overlap_sub_batches", 0)
-            eng.set_option("overlap_tail_streams", int(rng.integers(1, un // 4 + 1)))
+            eng.set_option("resident_blocks", int(rng.choice([1, 4, 8, 16])) * 16)
+        else:
+            eng.set_option("resident_blocks", int(rng.integers(1, un // 4 + 1)))
         ulen = int(rng.choice([128, 5000, 65535, 65536, 70000, 140000]))
         ud = flate.synth("text", un, ulen, first_stream=int(rng.integers(1 << 20)))
         uo = flate.uniform_offsets(un, ulen)
@@ -71,10 +70,10 @@ while time.time() - t0 < budget:
         ref, roff, rlen = O.deflate_batch(ud, uo, compat=cm, nthreads=8)
         for i in range(un):
             assert bytes(out[int(ooff[i]):int(ooff[i + 1])]) == bytes(ref[int(roff[i]):int(roff[i]) + int(rlen[i])]), \
-                "overlapped deflate stream %d differs (%s)" % (i, tag)
+                "uniform batch: deflate stream %d differs (%s)" % (i, tag)
         streams += un
         nbytes += un * ulen
-        eng.set_option("overlap_tail_streams", 0)
+        eng.set_option("resident_blocks", 1024)
     if rounds % 5 == 1:  # one of the round's streams through the piecewise decoder (flate_hip_inflate_stream_*)
         j = int(rng.integers(n))
         cj = out[int(ooff[j]):int(ooff[j + 1])] if rounds % 7 != 3 else None
