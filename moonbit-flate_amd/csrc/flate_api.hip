@@ -515,7 +515,19 @@ int flate_hip_init(int device, flate_hip_ctx **out) {
     return FLATE_HIP_E_NO_DEVICE;
   }
   c->stream = c->own_stream;
-  if (hipStreamCreateWithFlags(&c->guest_stream, hipStreamNonBlocking) != hipSuccess ||
+  // The match finder is TWO kernels that must run side by side (LDS-table blocks on c->stream, guest blocks
+  // on guest_stream, one queue of streams between them).  HIP spreads its streams over a few hardware
+  // queues (four by default) round robin; two streams that land on the same one run their kernels one
+  // after the other -- measured: the match finder of a sub-context 40 % slower (19.8 -> 27.9 ms per GiB in
+  // 4096-stream launches) when the number of streams created before it shifted by one.  Streams of a
+  // different PRIORITY come from a different pool of hardware queues, so the guest stream asks for one:
+  // it can never share a queue with the (normal-priority) stream of the kernel it runs beside.
+  int prio_least = 0, prio_greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+  const char *gp = getenv("FLATE_HIP_GUEST_STREAM_PRIORITY");  // (developer A/B: "normal" = as before)
+  const bool plain_guest = (gp && gp[0] == 'n') || prio_greatest == prio_least;
+  if ((plain_guest ? hipStreamCreateWithFlags(&c->guest_stream, hipStreamNonBlocking)
+                   : hipStreamCreateWithPriority(&c->guest_stream, hipStreamNonBlocking, prio_greatest)) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
     flate_hip_destroy(c);
@@ -981,9 +993,19 @@ void cut_by_bytes(const uint64_t *a, const uint64_t *b, uint32_t n, uint32_t G, 
   lo[G] = n;
 }
 
+// The two copy streams of the host-pointer pipelines: LOW priority, i.e. hardware queues of a pool of their
+// own (see the guest stream in flate_hip_init): a copy that shared a hardware queue with a lane's kernels
+// would wait behind them and the pipeline would run in lock step.
 int host_pipe_streams(flate_hip_ctx *c) {
-  if (!c->h2d_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking));
-  if (!c->d2h_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
+  int least = 0, greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+  const char *gp = getenv("FLATE_HIP_GUEST_STREAM_PRIORITY");
+  const bool plain = (gp && gp[0] == 'n') || least == greatest;
+  auto mk = [&](hipStream_t *s) {
+    return plain ? hipStreamCreateWithFlags(s, hipStreamNonBlocking) : hipStreamCreateWithPriority(s, hipStreamNonBlocking, least);
+  };
+  if (!c->h2d_stream) HIP_TRY(c, mk(&c->h2d_stream));
+  if (!c->d2h_stream) HIP_TRY(c, mk(&c->d2h_stream));
   return FLATE_HIP_OK;
 }
 }  // namespace
