@@ -725,6 +725,26 @@ def extra_legs(args, env):
                 "note": "same workload, input and output in HOST memory: the call copies 1 GiB in and %.2f GiB out "
                         "over PCIe, pipelined with the compression over groups of streams on two lanes; bytes "
                         "compared with the device-resident run (not the headline value)" % (clen / 2**30)}
+            # the containers' checksums of the same GiB (flate_hip_checksum_batch): one read of
+            # the input, the kernels' event time -- a kernel family that CAN be priced against the HBM roofline
+            if hasattr(eng, "checksum_batch"):
+                import zlib
+                sums = {}
+                for ck, ref in (("adler32", zlib.adler32), ("crc32", zlib.crc32)):
+                    eng.checksum_batch(d_in, in_off, ck)
+                    kms = []
+                    for _ in range(5):
+                        got = eng.checksum_batch(d_in, in_off, ck)
+                        kms.append(eng.last_timing()["checksum"])
+                    for i in range(0, n, 512):
+                        if int(got[i]) != ref(host[i * blen:(i + 1) * blen].tobytes()):
+                            raise SystemExit("checksum %s differs from zlib's at stream %d" % (ck, i))
+                    gbs = n * blen / (min(kms) * 1e-3) / 1e9
+                    sums[ck] = {"kernel_ms": summarize([k * 1e-3 for k in kms]), "GB_per_s": round(gbs, 1),
+                                "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                             "frac": round(gbs / HBM_PEAK_GBS, 4)},
+                                "checked_against_zlib_streams": len(range(0, n, 512))}
+                extra["container_checksums_16384x65536"] = sums
         del host, d_in
     extra["other_inputs_16384x65536"] = others
     del out

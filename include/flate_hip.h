@@ -259,6 +259,19 @@ int flate_hip_inflate_spliced(flate_hip_ctx *ctx, const uint8_t *in, uint64_t in
                               const uint64_t *out_off, uint64_t *out_len, int32_t *status,
                               int64_t *err_off, uint32_t flags);
 
+/* -- checksums for the container formats around a raw stream (optional gzip / zlib wrappers;
+ * the reference has neither) ------------------------------------------------------
+ * out[i] = the Adler-32 (RFC 1950 section 8.2: what a zlib stream carries behind its data, big endian) or
+ * the CRC-32 (RFC 1952 section 8: what a gzip member carries, little endian, followed by the length mod
+ * 2^32) of stream i = in[in_off[i], in_off[i+1]).  in: host, or device with FLATE_HIP_DEVICE_PTRS; in_off and
+ * out: host.  Streams of any length: the work is cut into 64 KiB pieces, so one long stream fills the chip
+ * as a batch of short ones does.  The framing itself -- two or ten header bytes, the trailer -- is the
+ * host mirrors' (flate_host::frame / unframe, FlateEngine.deflate_batch(..., wrap=)). */
+#define FLATE_HIP_CHECKSUM_ADLER32 1
+#define FLATE_HIP_CHECKSUM_CRC32 2
+int flate_hip_checksum_batch(flate_hip_ctx *ctx, const uint8_t *in, const uint64_t *in_off, uint32_t n_streams,
+                             uint32_t kind, uint32_t *out, uint32_t flags);
+
 /* -- splice ---------------------------------------------------------------------
  * SURVEY 8(f)-3; no counterpart in the reference, whose Writer makes one stream per
  * Writer.  Same compression as flate_hip_deflate_fast_batch (stream i is encoded as a
@@ -345,7 +358,7 @@ int flate_hip_gather_end(flate_hip_comm *comm, uint64_t *stream_off, uint64_t *s
  * milliseconds of the last call (stage names via flate_hip_stage_name). */
 #define FLATE_HIP_STAGE_LZ77 0
 #define FLATE_HIP_STAGE_HUFF_PACK 1
-#define FLATE_HIP_STAGE_COMPACT 2 /* unused: the pack kernel writes in place */
+#define FLATE_HIP_STAGE_CHECKSUM 2 /* flate_hip_checksum_batch (the slot was "compact", never used) */
 #define FLATE_HIP_STAGE_INFLATE 3
 #define FLATE_HIP_STAGE_COUNT 4
 int flate_hip_set_profiling(flate_hip_ctx *ctx, int on);

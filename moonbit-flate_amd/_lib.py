@@ -20,7 +20,7 @@ EXPORTS = [
     "flate_hip_stream_open", "flate_hip_stream_bound", "flate_hip_stream_write", "flate_hip_stream_free",
     "flate_hip_host_register", "flate_hip_host_unregister", "flate_hip_host_alloc", "flate_hip_host_free",
     "flate_hip_inflate_stream_open", "flate_hip_inflate_stream_read", "flate_hip_inflate_stream_free",
-    "flate_hip_inflate_stream_reset",
+    "flate_hip_inflate_stream_reset", "flate_hip_checksum_batch",
 ]
 
 _lib = None
@@ -100,6 +100,7 @@ def load():
     L.flate_hip_inflate_stream_read.argtypes = [vp, vp, C.c_uint64, C.c_int, vp, C.c_uint64, u64p, u64p,
                                                 C.POINTER(C.c_int64)]
     L.flate_hip_inflate_stream_reset.argtypes = [vp, vp, C.c_uint64]
+    L.flate_hip_checksum_batch.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint32]
     L.flate_hip_inflate_stream_free.argtypes = [vp]
     L.flate_hip_inflate_stream_free.restype = None
     L.flate_hip_host_register.argtypes = [vp, vp, C.c_size_t]

@@ -10,14 +10,16 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libflate_hip.so")
 
 SOURCES = ["lz77_kernels.hip",  "huff_pack_kernels.hip", "compact_kernels.hip",
-           "inflate_kernels.hip", "splice_kernels.hip", "flate_api.hip", "gather.hip", "synth.cpp"]
-HEADERS = ["flate_common.h", "flate_kernels.h", "lz77_device.h", "inflate_spec_kernel.inc", os.path.join(ROOT, "include", "flate_hip.h")]
+           "inflate_kernels.hip", "splice_kernels.hip", "flate_api.hip", "gather.hip", "checksum.hip", "synth.cpp"]
+HEADERS = ["flate_common.h", "flate_kernels.h", "lz77_device.h", "inflate_spec_kernel.inc", "inflate_stream_kernel.inc",
+           os.path.join(ROOT, "include", "flate_hip.h")]
 
 
 GROUPS = {  # which sources a kernel family's measurements depend on (besides the shared headers / ABI)
     "lz77": ["lz77_kernels.hip", "lz77_device.h"],
     "huff": ["huff_pack_kernels.hip", "compact_kernels.hip", "splice_kernels.hip"],
-    "inflate": ["inflate_kernels.hip", "inflate_spec_kernel.inc"],
+    "inflate": ["inflate_kernels.hip", "inflate_spec_kernel.inc", "inflate_stream_kernel.inc"],
+    "checksum": ["checksum.hip"],
 }
 SHARED = ["flate_common.h", "flate_kernels.h", "flate_api.hip"]
 

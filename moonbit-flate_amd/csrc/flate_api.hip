@@ -122,6 +122,22 @@ namespace flate {
 hipStream_t ctx_stream(flate_hip_ctx *c) { return c->stream; }
 int ctx_device(flate_hip_ctx *c) { return c->device; }
 void ctx_set_error(flate_hip_ctx *c, const std::string &msg) { c->hip_err = msg; }
+uint32_t ctx_num_cus(flate_hip_ctx *c) { return c->num_cus; }
+void ctx_stage_begin(flate_hip_ctx *c, int stage) {
+  if (c->profiling) (void)hipEventRecord(c->ev[2 * stage], c->stream);
+}
+void ctx_stage_end(flate_hip_ctx *c, int stage) {
+  if (c->profiling) (void)hipEventRecord(c->ev[2 * stage + 1], c->stream);
+}
+int ctx_stage_collect(flate_hip_ctx *c, int stage) {
+  for (int s = 0; s < FLATE_HIP_STAGE_COUNT; ++s) c->stage_ms[s] = 0.f;
+  if (c->profiling) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev[2 * stage], c->ev[2 * stage + 1]) != hipSuccess) return FLATE_HIP_E_HIP;
+    c->stage_ms[stage] = ms;
+  }
+  return FLATE_HIP_OK;
+}
 }  // namespace flate
 
 namespace {
@@ -496,7 +512,7 @@ const char *flate_hip_stage_name(int stage) {
   switch (stage) {
     case FLATE_HIP_STAGE_LZ77: return "lz77_match";
     case FLATE_HIP_STAGE_HUFF_PACK: return "huff_pack";
-    case FLATE_HIP_STAGE_COMPACT: return "compact";  // unused since the pack kernel writes in place
+    case FLATE_HIP_STAGE_CHECKSUM: return "checksum";
     case FLATE_HIP_STAGE_INFLATE: return "inflate";
     default: return "?";
   }

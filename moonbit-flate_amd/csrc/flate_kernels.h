@@ -193,4 +193,10 @@ namespace flate {
 hipStream_t ctx_stream(flate_hip_ctx *c);
 int ctx_device(flate_hip_ctx *c);
 void ctx_set_error(flate_hip_ctx *c, const std::string &msg);
+uint32_t ctx_num_cus(flate_hip_ctx *c);
+// one stage's kernels between two events of the ctx (when profiling is on); ctx_stage_collect after the
+// stream has been synchronised: stage_ms[stage] from them, every other stage zero
+void ctx_stage_begin(flate_hip_ctx *c, int stage);
+void ctx_stage_end(flate_hip_ctx *c, int stage);
+int ctx_stage_collect(flate_hip_ctx *c, int stage);
 }  // namespace flate

@@ -20,7 +20,7 @@ SYNTH_KINDS = {"ramp": SYNTH_RAMP, "text": SYNTH_TEXT, "rand": SYNTH_RAND, "zero
 SEED_TEXT = 0x5EED0001
 SEED_RAND = 0x5EED0002
 
-STAGES = ("lz77_match", "huff_pack", "compact", "inflate")
+STAGES = ("lz77_match", "huff_pack", "checksum", "inflate")
 
 MAX_STORE_BLOCK_SIZE = 65535
 MATCH_CAP_PER_CHUNK = 16384
@@ -195,6 +195,99 @@ class FlateEngine:
                                                   self._flags(compat_go, lz_serial, device))
         self._check(rc)
         return out, out_off
+
+    def checksum_batch(self, data, in_off, kind="adler32"):
+        """Adler-32 (RFC 1950) or CRC-32 (RFC 1952) of every stream data[in_off[i]:in_off[i+1]] -> numpy uint32[n]
+        (flate_hip_checksum_batch; numpy data = host pointers, torch CUDA tensor = device pointers)."""
+        in_off = np.ascontiguousarray(in_off, dtype=np.uint64)
+        n = in_off.size - 1
+        out = np.zeros(max(n, 1), dtype=np.uint32)
+        device = _is_torch(data)
+        if device:
+            ptr = data.data_ptr()
+        else:
+            data = np.ascontiguousarray(data, dtype=np.uint8)
+            ptr = data.ctypes.data if data.size else None
+        k = {"adler32": CHECKSUM_ADLER32, "crc32": CHECKSUM_CRC32}[kind]
+        self._check(self._L.flate_hip_checksum_batch(self._ctx, ptr, in_off.ctypes.data, n, k, out.ctypes.data,
+                                                     DEVICE_PTRS if device else 0))
+        return out[:n]
+
+    def deflate_batch_framed(self, data, in_off, wrap, compat_go=False):
+        """The streams of a batch as zlib (RFC 1950) or gzip (RFC 1952) members: the raw DEFLATE streams of
+        deflate_batch between the container's header and its trailer -- Adler-32, or CRC-32 and the length,
+        computed on the GPU (flate_hip_checksum_batch).  Host data; returns (bytes array, off[n+1])."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        in_off = np.ascontiguousarray(in_off, dtype=np.uint64)
+        n = in_off.size - 1
+        raw, roff = self.deflate_batch(data, in_off, compat_go=compat_go)
+        sums = self.checksum_batch(data, in_off, "adler32" if wrap == "zlib" else "crc32")
+        head = ZLIB_HEADER if wrap == "zlib" else GZIP_HEADER
+        tail = 4 if wrap == "zlib" else 8
+        off = roff + np.arange(n + 1, dtype=np.uint64) * np.uint64(len(head) + tail)
+        out = np.empty(int(off[-1]), dtype=np.uint8)
+        lens = (in_off[1:] - in_off[:-1]).astype(np.uint64)
+        for i in range(n):
+            o = int(off[i])
+            out[o:o + len(head)] = np.frombuffer(head, np.uint8)
+            o += len(head)
+            k = int(roff[i + 1] - roff[i])
+            out[o:o + k] = raw[int(roff[i]):int(roff[i + 1])]
+            o += k
+            if wrap == "zlib":
+                out[o:o + 4] = np.frombuffer(int(sums[i]).to_bytes(4, "big"), np.uint8)
+            else:
+                out[o:o + 8] = np.frombuffer(int(sums[i]).to_bytes(4, "little") +
+                                             (int(lens[i]) & 0xFFFFFFFF).to_bytes(4, "little"), np.uint8)
+        return out, off
+
+    def inflate_batch_framed(self, data, in_off, wrap, out_sizes=None):
+        """The reverse: zlib or gzip members -> (out, out_off, status[n]); status -4 (FLATE_HIP_E_CORRUPT) also
+        for a bad header, a checksum or (gzip) a length that does not match.  zlib members carry no size:
+        out_sizes (or a size-only pass of the decoder) supplies it; gzip's ISIZE is used as the slot size."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        in_off = np.ascontiguousarray(in_off, dtype=np.uint64)
+        n = in_off.size - 1
+        start = np.zeros(n + 1, dtype=np.uint64)
+        want = np.zeros(n, dtype=np.uint32)
+        isize = np.zeros(n, dtype=np.uint64)
+        bad = np.zeros(n, dtype=bool)
+        for i in range(n):
+            a, b = int(in_off[i]), int(in_off[i + 1])
+            m = data[a:b]
+            h, t = parse_container_header(m, wrap)
+            if h < 0 or b - a < h + t:
+                bad[i] = True
+                h = 0
+            else:
+                tr = bytes(m[len(m) - t:])
+                want[i] = int.from_bytes(tr[:4], "big" if wrap == "zlib" else "little")
+                if wrap == "gzip":
+                    isize[i] = int.from_bytes(tr[4:8], "little")
+            start[i] = a + h
+        start[n] = in_off[n]
+        src = np.concatenate([data[:int(in_off[n])], np.zeros(8, np.uint8)])
+        if out_sizes is None:
+            if wrap == "gzip":
+                out_sizes = isize
+            else:
+                out_sizes, _, _ = self.inflate_sizes(src, start)
+        out, ooff, olen, status, _ = self.inflate_batch(src, start, out_sizes, check=False)
+        sums = self.checksum_batch(out, ooff, "adler32" if wrap == "zlib" else "crc32") if n else np.zeros(0, np.uint32)
+        status = np.array(status, dtype=np.int32)
+        for i in range(n):
+            if bad[i]:
+                status[i] = E_CORRUPT
+            elif status[i] == 0:
+                # (a slot larger than the member's output: the checksum is over the bytes produced)
+                if int(olen[i]) != int(ooff[i + 1] - ooff[i]):
+                    s = self.checksum_batch(out[int(ooff[i]):int(ooff[i]) + int(olen[i])], [0, int(olen[i])],
+                                            "adler32" if wrap == "zlib" else "crc32")[0]
+                else:
+                    s = sums[i]
+                if int(s) != int(want[i]) or (wrap == "gzip" and (int(olen[i]) & 0xFFFFFFFF) != int(isize[i])):
+                    status[i] = E_CORRUPT
+        return out, ooff, olen, status
 
     def inflate_batch(self, data, in_off, out_sizes, out=None, check=True):
         """Decompress independent DEFLATE streams (&Reader::new + read to EOF each).
@@ -452,6 +545,38 @@ class StreamReader:
             self.free()
         except Exception:
             pass
+
+
+CHECKSUM_ADLER32, CHECKSUM_CRC32 = 1, 2
+ZLIB_HEADER = bytes([0x78, 0x01])  # CM = 8, CINFO = 7 (32 KiB window), FLEVEL = 0 (fastest), FCHECK (RFC 1950 2.2)
+GZIP_HEADER = bytes([0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 4, 255])  # no name / time, XFL = 4 (fastest), OS unknown (RFC 1952 2.3)
+
+
+def parse_container_header(m, wrap):
+    """(header bytes, trailer bytes) of one zlib / gzip member, or (-1, 0) if its header is not valid
+    (RFC 1950 2.2: CM = 8, window <= 32 KiB, FCHECK, no preset dictionary; RFC 1952 2.3: magic, CM = 8,
+    reserved flag bits zero, the optional fields skipped)."""
+    m = bytes(m[:min(len(m), 70000)])
+    if wrap == "zlib":
+        if len(m) < 2 or (m[0] & 15) != 8 or (m[0] >> 4) > 7 or ((m[0] << 8) | m[1]) % 31 or (m[1] & 0x20):
+            return -1, 0
+        return 2, 4
+    if len(m) < 10 or m[0] != 0x1f or m[1] != 0x8b or m[2] != 8 or (m[3] & 0xe0):
+        return -1, 0
+    flg, p = m[3], 10
+    if flg & 4:  # FEXTRA
+        if len(m) < p + 2:
+            return -1, 0
+        p += 2 + int.from_bytes(m[p:p + 2], "little")
+    for bit in (8, 16):  # FNAME, FCOMMENT: zero-terminated
+        if flg & bit:
+            z = m.find(b"\0", p)
+            if z < 0:
+                return -1, 0
+            p = z + 1
+    if flg & 2:  # FHCRC
+        p += 2
+    return (p, 8) if p <= len(m) else (-1, 0)
 
 
 # status codes of inflate_batch (include/flate_hip.h)

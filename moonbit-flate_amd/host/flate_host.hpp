@@ -100,6 +100,57 @@ inline Err compress_batch(Engine &e, const std::vector<std::vector<uint8_t>> &st
   return std::nullopt;
 }
 
+// The container formats around a raw stream (the reference has neither): zlib (RFC 1950: CMF, FLG,
+// data, Adler-32 big endian) and gzip (RFC 1952: ten header bytes, data, CRC-32 and length little endian).
+// The checksums come from the GPU (flate_hip_checksum_batch), the framing is these few bytes.
+enum class Wrap { Raw, Zlib, Gzip };
+
+inline Err checksum_batch(Engine &e, const std::vector<std::vector<uint8_t>> &streams, uint32_t kind,
+                          std::vector<uint32_t> &sums) {
+  if (!e.ok()) return make_error(e, e.status());
+  const uint32_t n = (uint32_t)streams.size();
+  std::vector<uint64_t> in_off(n + 1, 0);
+  for (uint32_t i = 0; i < n; ++i) in_off[i + 1] = in_off[i] + streams[i].size();
+  std::vector<uint8_t> in(in_off[n] + 1);
+  for (uint32_t i = 0; i < n; ++i) std::copy(streams[i].begin(), streams[i].end(), in.begin() + in_off[i]);
+  sums.assign(n, 0);
+  const int rc = flate_hip_checksum_batch(e.ctx(), in.data(), in_off.data(), n, kind, sums.data(), 0);
+  if (rc != 0) return make_error(e, rc);
+  return std::nullopt;
+}
+
+// compress_batch with every stream inside its container
+inline Err compress_batch(Engine &e, const std::vector<std::vector<uint8_t>> &streams,
+                          std::vector<std::vector<uint8_t>> &out, Wrap wrap, uint32_t flags = 0) {
+  std::vector<std::vector<uint8_t>> raw;
+  if (Err er = compress_batch(e, streams, raw, flags)) return er;
+  if (wrap == Wrap::Raw) {
+    out = std::move(raw);
+    return std::nullopt;
+  }
+  std::vector<uint32_t> sums;
+  if (Err er = checksum_batch(e, streams, wrap == Wrap::Zlib ? FLATE_HIP_CHECKSUM_ADLER32 : FLATE_HIP_CHECKSUM_CRC32, sums))
+    return er;
+  static const uint8_t zhead[2] = {0x78, 0x01};  // CM = 8, 32 KiB window; FLEVEL = 0 (fastest), FCHECK
+  static const uint8_t ghead[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 4 /* XFL: fastest */, 255 /* OS: unknown */};
+  out.resize(raw.size());
+  for (size_t i = 0; i < raw.size(); ++i) {
+    std::vector<uint8_t> &m = out[i];
+    m.clear();
+    if (wrap == Wrap::Zlib) {
+      m.insert(m.end(), zhead, zhead + 2);
+      m.insert(m.end(), raw[i].begin(), raw[i].end());
+      for (int k = 3; k >= 0; --k) m.push_back((uint8_t)(sums[i] >> (8 * k)));
+    } else {
+      m.insert(m.end(), ghead, ghead + 10);
+      m.insert(m.end(), raw[i].begin(), raw[i].end());
+      for (int k = 0; k < 4; ++k) m.push_back((uint8_t)(sums[i] >> (8 * k)));
+      for (int k = 0; k < 4; ++k) m.push_back((uint8_t)((uint32_t)streams[i].size() >> (8 * k)));
+    }
+  }
+  return std::nullopt;
+}
+
 inline Err compress_spliced(Engine &e, const std::vector<std::vector<uint8_t>> &streams,
                             std::vector<uint8_t> &out, std::vector<uint64_t> *bit_off, uint32_t flags);
 

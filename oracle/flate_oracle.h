@@ -140,4 +140,13 @@ int orc_deflate_spliced(const uint8_t *in, const uint64_t *in_off, uint32_t n_st
 #ifdef __cplusplus
 }
 #endif
+/* -- checksum.c: the checksums and container formats around a raw stream (RFC 1950 / RFC 1952) -- */
+#define ORC_FRAME_RAW 0
+#define ORC_FRAME_ZLIB 1
+#define ORC_FRAME_GZIP 2
+uint32_t orc_adler32(const uint8_t *p, size_t n);
+uint32_t orc_crc32(const uint8_t *p, size_t n);
+size_t orc_frame_overhead(int kind);
+size_t orc_frame(int kind, const uint8_t *raw, size_t raw_len, const uint8_t *data, size_t n, uint8_t *out);
+
 #endif

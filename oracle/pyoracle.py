@@ -57,6 +57,14 @@ def lib():
                                               C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
                                               C.POINTER(C.c_longlong)]
         L.orc_inflate_stream_dict.restype = C.c_int
+        L.orc_adler32.argtypes = [C.c_void_p, C.c_size_t]
+        L.orc_adler32.restype = C.c_uint32
+        L.orc_crc32.argtypes = [C.c_void_p, C.c_size_t]
+        L.orc_crc32.restype = C.c_uint32
+        L.orc_frame_overhead.argtypes = [C.c_int]
+        L.orc_frame_overhead.restype = C.c_size_t
+        L.orc_frame.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.orc_frame.restype = C.c_size_t
         L.orc_deflate_bound.argtypes = [C.c_size_t]
         L.orc_deflate_bound.restype = C.c_size_t
         L.orc_df_new.argtypes = [C.c_int]
@@ -242,3 +250,27 @@ def deflate_batch(in_buf, in_off, compat=COMPAT_MOONBIT, nthreads=1):
     if rc != 0:
         raise RuntimeError("oracle batch deflate failed: %d" % rc)
     return out, out_off, out_len
+
+
+FRAME_RAW, FRAME_ZLIB, FRAME_GZIP = 0, 1, 2
+
+
+def adler32(data):
+    a = _as_u8(data)
+    return int(lib().orc_adler32(a.ctypes.data if a.size else None, a.size))
+
+
+def crc32(data):
+    a = _as_u8(data)
+    return int(lib().orc_crc32(a.ctypes.data if a.size else None, a.size))
+
+
+def frame(kind, raw, data):
+    """The raw DEFLATE stream `raw` of `data` inside a zlib (RFC 1950) or gzip (RFC 1952) container."""
+    L = lib()
+    r, d = _as_u8(raw), _as_u8(data)
+    out = np.empty(r.size + L.orc_frame_overhead(kind) + 1, dtype=np.uint8)
+    n = L.orc_frame(kind, r.ctypes.data if r.size else None, r.size, d.ctypes.data if d.size else None, d.size,
+                    out.ctypes.data)
+    return out[:n].tobytes()
+

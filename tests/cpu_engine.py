@@ -6,7 +6,7 @@ import numpy as np
 
 from oracle import pyoracle
 
-STAGES = ("lz77_match", "huff_pack", "compact", "inflate")
+STAGES = ("lz77_match", "huff_pack", "checksum", "inflate")
 
 
 class OracleEngine:

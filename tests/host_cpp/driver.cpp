@@ -64,6 +64,16 @@ int main(int argc, char **argv) {
   if (!be)
     for (size_t i = 0; i < out.size(); ++i) hex("stream", out[i]);
 
+  // the same three streams as zlib and as gzip members (checksums from the GPU)
+  {
+    std::vector<std::vector<uint8_t>> z, g;
+    Err ze = compress_batch(eng, in, z, Wrap::Zlib);
+    Err ge = compress_batch(eng, in, g, Wrap::Gzip);
+    printf("framed %s %s\n", ze ? ze->msg.c_str() : "none", ge ? ge->msg.c_str() : "none");
+    for (size_t i = 0; i < z.size(); ++i) hex("zlibm", z[i]);
+    for (size_t i = 0; i < g.size(); ++i) hex("gzipm", g[i]);
+  }
+
   // &Reader::new + read in 7-byte pieces + close (inflate.mbt:305,382-405,410-415)
   {
     BytesReader src(b.bytes);

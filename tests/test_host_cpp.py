@@ -45,10 +45,14 @@ def test_host_mirror_matches_reference_behaviour(oracle):
     os.unlink(case.name)
     assert out.returncode == 0, out.stdout + out.stderr
     lines = dict()
-    streams, reads = [], []
+    streams, reads, zmem, gmem = [], [], [], []
     for ln in out.stdout.splitlines():
         k, _, v = ln.partition(" ")
-        if k == "stream":
+        if k == "zlibm":
+            zmem.append(bytes.fromhex(v))
+        elif k == "gzipm":
+            gmem.append(bytes.fromhex(v))
+        elif k == "stream":
             streams.append(bytes.fromhex(v))
         elif k == "read":
             reads.append(v)
@@ -67,6 +71,12 @@ def test_host_mirror_matches_reference_behaviour(oracle):
     assert streams[0] == oracle.deflate(b"") == bytes([1, 0, 0, 0xFF, 0xFF])
     assert streams[1] == oracle.deflate(ramp)
     assert streams[2] == oracle.deflate(bytes(100))
+    # the same streams inside zlib / gzip containers: the oracle's frames, and zlib's own decoders accept them
+    import gzip as gzip_mod
+    assert lines["framed"] == "none none"
+    for i, plain in enumerate((b"", ramp.tobytes(), bytes(100))):
+        assert zmem[i] == oracle.frame(oracle.FRAME_ZLIB, streams[i], plain) and zlib.decompress(zmem[i]) == plain
+        assert gmem[i] == oracle.frame(oracle.FRAME_GZIP, streams[i], plain) and gzip_mod.decompress(gmem[i]) == plain
     # Decompressor::read hands out data first and the error with the last bytes (inflate.mbt:382-405)
     assert reads == ["7 none", "7 none", "7 none", "7 EOF", "0 EOF", "0 EOF", "0 EOF"]
     assert lines["rclose"] == "none"                                    # :410-415

@@ -8,5 +8,5 @@ C=moonbit-flate_amd/csrc
 mkdir -p build/exp
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -Iinclude -I$C "$@" \
   $C/lz77_kernels.hip $C/huff_pack_kernels.hip $C/compact_kernels.hip $C/inflate_kernels.hip \
-  $C/splice_kernels.hip $C/flate_api.hip $C/gather.hip $C/synth.cpp -o build/exp/lib$name.so -lpthread -ldl
+  $C/splice_kernels.hip $C/flate_api.hip $C/gather.hip $C/checksum.hip $C/synth.cpp -o build/exp/lib$name.so -lpthread -ldl
 echo build/exp/lib$name.so
