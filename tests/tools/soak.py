@@ -74,6 +74,23 @@ while time.time() - t0 < budget:
         streams += un
         nbytes += un * ulen
         eng.set_option("resident_blocks", 1024)
+    if rounds % 4 == 2:  # the containers' checksums of the round's streams, and a framed round trip
+        import zlib as _z
+        kind = ("adler32", "crc32")[(rounds >> 2) & 1]
+        got = eng.checksum_batch(data, off, kind)
+        for i in range(n):
+            d_i = data[int(off[i]):int(off[i + 1])].tobytes()
+            assert int(got[i]) == (_z.adler32 if kind == "adler32" else _z.crc32)(d_i), "checksum %s of stream %d (%s)" % (kind, i, tag)
+        if rounds % 8 == 2:
+            wrap = "zlib" if kind == "adler32" else "gzip"
+            fr, fo = eng.deflate_batch_framed(data, off, wrap, compat_go=go)
+            j = int(rng.integers(n))
+            m = fr[int(fo[j]):int(fo[j + 1])].tobytes()
+            want_j = data[int(off[j]):int(off[j + 1])].tobytes()
+            import gzip as _g
+            assert (_z.decompress(m) if wrap == "zlib" else _g.decompress(m)) == want_j, "framed member %d (%s)" % (j, tag)
+            bo, boff, bl, bst = eng.inflate_batch_framed(fr, fo, wrap, out_sizes=szs)
+            assert (bst == 0).all() and bytes(bo[:int(off[-1])]) == data[:int(off[-1])].tobytes(), "framed round trip (%s)" % tag
     if rounds % 5 == 1:  # one of the round's streams through the piecewise decoder (flate_hip_inflate_stream_*)
         j = int(rng.integers(n))
         cj = out[int(ooff[j]):int(ooff[j + 1])] if rounds % 7 != 3 else None
