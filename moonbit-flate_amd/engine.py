@@ -241,6 +241,21 @@ class FlateEngine:
                                              (int(lens[i]) & 0xFFFFFFFF).to_bytes(4, "little"), np.uint8)
         return out, off
 
+    def deflate_spliced_framed(self, data, in_off, wrap, compat_go=False):
+        """The whole batch as ONE zlib stream or ONE gzip member: the spliced DEFLATE stream of deflate_spliced
+        (every input stream compressed on its own, in parallel, joined at bit granularity) between the
+        container's header and the checksum of ALL the input -- what `gzip -d` / zlib.decompress turn back
+        into the concatenated input.  Host data; returns bytes."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        in_off = np.ascontiguousarray(in_off, dtype=np.uint64)
+        one, nbytes, _ = self.deflate_spliced(data, in_off, compat_go=compat_go)
+        total = int(in_off[-1] - in_off[0])
+        whole = np.array([in_off[0], in_off[-1]], dtype=np.uint64)
+        s = int(self.checksum_batch(data, whole, "adler32" if wrap == "zlib" else "crc32")[0])
+        if wrap == "zlib":
+            return ZLIB_HEADER + bytes(one[:int(nbytes)]) + s.to_bytes(4, "big")
+        return GZIP_HEADER + bytes(one[:int(nbytes)]) + s.to_bytes(4, "little") + (total & 0xFFFFFFFF).to_bytes(4, "little")
+
     def inflate_batch_framed(self, data, in_off, wrap, out_sizes=None):
         """The reverse: zlib or gzip members -> (out, out_off, status[n]); status -4 (FLATE_HIP_E_CORRUPT) also
         for a bad header, a checksum or (gzip) a length that does not match.  zlib members carry no size:

@@ -119,3 +119,14 @@ def test_framed_batches(eng, oracle, wrap):
     out, ooff, olen, status = eng.inflate_batch_framed(np.frombuffer(bytes(bad), np.uint8), foff, wrap,
                                                         out_sizes=[n for _, n in specs])
     assert status[0] == -4 and status[1] == -4 and (status[2:] == 0).all()
+
+
+@pytest.mark.gpu
+def test_whole_batch_as_one_gzip_member_and_one_zlib_stream(eng):
+    # every stream compressed on its own, in parallel, spliced into ONE DEFLATE stream -- and framed as one file
+    specs = [("text", 65536)] * 40 + [("rand", 70000), ("text", 0), ("zero", 300000), ("text", 17)]
+    data, off = make_streams(specs, seed=9)
+    plain = data[:int(off[-1])].tobytes()
+    assert gzip.decompress(eng.deflate_spliced_framed(data, off, "gzip")) == plain
+    assert zlib.decompress(eng.deflate_spliced_framed(data, off, "zlib")) == plain
+
