@@ -398,6 +398,74 @@ inline Err decompress_batch(Engine &e, const std::vector<std::vector<uint8_t>> &
   return std::nullopt;
 }
 
+// header / trailer bytes of one zlib or gzip member, {-1, 0} if its header is not one (RFC 1950 2.2: CM = 8,
+// window <= 32 KiB, FCHECK, no preset dictionary; RFC 1952 2.3: magic, CM = 8, reserved flag bits zero, the
+// optional fields skipped)
+inline std::pair<int, int> container_header(const std::vector<uint8_t> &m, Wrap wrap) {
+  if (wrap == Wrap::Zlib) {
+    if (m.size() < 2 || (m[0] & 15) != 8 || (m[0] >> 4) > 7 || ((m[0] << 8) | m[1]) % 31 || (m[1] & 0x20)) return {-1, 0};
+    return {2, 4};
+  }
+  if (m.size() < 10 || m[0] != 0x1f || m[1] != 0x8b || m[2] != 8 || (m[3] & 0xe0)) return {-1, 0};
+  const uint8_t flg = m[3];
+  size_t p = 10;
+  if (flg & 4) {  // FEXTRA
+    if (m.size() < p + 2) return {-1, 0};
+    p += 2 + (size_t)(m[p] | (m[p + 1] << 8));
+  }
+  for (int bit : {8, 16})  // FNAME, FCOMMENT: zero-terminated
+    if (flg & bit) {
+      while (p < m.size() && m[p]) ++p;
+      if (p >= m.size()) return {-1, 0};
+      ++p;
+    }
+  if (flg & 2) p += 2;  // FHCRC
+  return p <= m.size() ? std::pair<int, int>{(int)p, 8} : std::pair<int, int>{-1, 0};
+}
+
+// decompress_batch for zlib / gzip members: the raw streams decoded on the GPU, the trailers checked against the
+// checksums of what came out (flate_hip_checksum_batch); a bad header, checksum or (gzip) length is
+// corrupt_input_error at the member's end.  sizes[i] = capacity for member i's output (gzip: 0 = its ISIZE).
+inline Err decompress_batch(Engine &e, const std::vector<std::vector<uint8_t>> &members, std::vector<uint64_t> sizes,
+                            std::vector<Inflated> &out, Wrap wrap) {
+  if (wrap == Wrap::Raw) return decompress_batch(e, members, sizes, out);
+  const size_t n = members.size();
+  std::vector<std::vector<uint8_t>> raw(n);
+  std::vector<uint32_t> want(n, 0), isize(n, 0);
+  std::vector<bool> bad(n, false);
+  sizes.resize(n, 0);
+  for (size_t i = 0; i < n; ++i) {
+    const auto ht = container_header(members[i], wrap);
+    if (ht.first < 0 || members[i].size() < (size_t)(ht.first + ht.second)) {
+      bad[i] = true;
+      continue;
+    }
+    raw[i].assign(members[i].begin() + ht.first, members[i].end() - ht.second);
+    const uint8_t *t = members[i].data() + members[i].size() - ht.second;
+    if (wrap == Wrap::Zlib) {
+      want[i] = ((uint32_t)t[0] << 24) | ((uint32_t)t[1] << 16) | ((uint32_t)t[2] << 8) | t[3];
+    } else {
+      want[i] = t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+      isize[i] = t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+      if (sizes[i] == 0) sizes[i] = isize[i];
+    }
+  }
+  if (Err er = decompress_batch(e, raw, sizes, out)) return er;
+  std::vector<std::vector<uint8_t>> plain(n);
+  for (size_t i = 0; i < n; ++i) plain[i] = out[i].bytes;
+  std::vector<uint32_t> sums;
+  if (Err er = checksum_batch(e, plain, wrap == Wrap::Zlib ? FLATE_HIP_CHECKSUM_ADLER32 : FLATE_HIP_CHECKSUM_CRC32, sums)) return er;
+  for (size_t i = 0; i < n; ++i) {
+    const bool mismatch = !bad[i] && out[i].status == 0 &&
+                          (sums[i] != want[i] || (wrap == Wrap::Gzip && (uint32_t)out[i].bytes.size() != isize[i]));
+    if (bad[i] || mismatch) {
+      out[i].status = FLATE_HIP_E_CORRUPT;
+      out[i].err = corrupt_input_error(bad[i] ? 0 : (int64_t)members[i].size());
+    }
+  }
+  return std::nullopt;
+}
+
 // &Reader (inflate.mbt:227-232): where a Decompressor pulls its input from
 struct ByteSource {
   virtual ~ByteSource() = default;

@@ -72,6 +72,18 @@ int main(int argc, char **argv) {
     printf("framed %s %s\n", ze ? ze->msg.c_str() : "none", ge ? ge->msg.c_str() : "none");
     for (size_t i = 0; i < z.size(); ++i) hex("zlibm", z[i]);
     for (size_t i = 0; i < g.size(); ++i) hex("gzipm", g[i]);
+    // and back; member 1 of the gzip batch with a damaged CRC, member 2 of the zlib batch with a bad header
+    if (g.size() == 3 && z.size() == 3) {
+      g[1][g[1].size() - 6] ^= 0x10;
+      z[2][0] = 0x79;
+      std::vector<Inflated> zb, gb;
+      Err e1 = decompress_batch(eng, z, {0, 65536, 100}, zb, Wrap::Zlib);
+      Err e2 = decompress_batch(eng, g, {}, gb, Wrap::Gzip);
+      printf("unframed %s %s", e1 ? e1->msg.c_str() : "none", e2 ? e2->msg.c_str() : "none");
+      for (auto *b : {&zb, &gb})
+        for (size_t i = 0; i < b->size(); ++i) printf(" %d:%zu", (*b)[i].status, (*b)[i].bytes.size());
+      printf("\n");
+    }
   }
 
   // &Reader::new + read in 7-byte pieces + close (inflate.mbt:305,382-405,410-415)

@@ -74,6 +74,8 @@ def test_host_mirror_matches_reference_behaviour(oracle):
     # the same streams inside zlib / gzip containers: the oracle's frames, and zlib's own decoders accept them
     import gzip as gzip_mod
     assert lines["framed"] == "none none"
+    # ... and decoded again: zlib members 0, 1 fine, 2 has a bad header; gzip member 1 has a damaged CRC
+    assert lines["unframed"] == "none none 0:0 0:65536 -4:0 0:0 -4:65536 0:100"
     for i, plain in enumerate((b"", ramp.tobytes(), bytes(100))):
         assert zmem[i] == oracle.frame(oracle.FRAME_ZLIB, streams[i], plain) and zlib.decompress(zmem[i]) == plain
         assert gmem[i] == oracle.frame(oracle.FRAME_GZIP, streams[i], plain) and gzip_mod.decompress(gmem[i]) == plain

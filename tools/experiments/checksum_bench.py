@@ -17,3 +17,11 @@ for name, off in (("16384 streams", flate.uniform_offsets(n, blen)), ("one strea
             eng.checksum_batch(d, off, kind)
             ts.append(eng.last_timing()["checksum"])
         print("%-14s %-8s kernel ms %s  -> %.0f GB/s" % (name, kind, ["%.3f" % t for t in ts], n * blen / min(ts) / 1e6), flush=True)
+import time
+off = flate.uniform_offsets(n, blen)
+for kind in ("adler32", "crc32"):
+    eng.checksum_batch(d, off, kind)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        eng.checksum_batch(d, off, kind)
+    print("wall per call (16384 streams, device pointers) %-8s %.3f ms" % (kind, (time.perf_counter() - t0) / 20 * 1e3), flush=True)
