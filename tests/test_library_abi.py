@@ -37,6 +37,15 @@ def test_strerror_and_bound(lib):
     assert flate.deflate_bound(65536) >= 65536 + 10
 
 
+def test_checksum_batch_refuses_bad_arguments_before_it_touches_a_device(lib):
+    off = (C.c_uint64 * 2)(0, 4)
+    out = (C.c_uint32 * 1)()
+    buf = (C.c_uint8 * 4)(1, 2, 3, 4)
+    assert lib.flate_hip_checksum_batch(None, buf, off, 1, 1, out, 0) == -1      # no ctx
+    # (kind, offsets and pointers are checked in front of any HIP call as well; that needs a ctx, i.e. a GPU:
+    # tests/test_checksum.py)
+
+
 def test_no_gpu_means_loud_failure(lib):
     import torch
     if torch.cuda.is_available():
