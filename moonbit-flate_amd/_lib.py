@@ -100,7 +100,9 @@ def load():
     L.flate_hip_inflate_stream_read.argtypes = [vp, vp, C.c_uint64, C.c_int, vp, C.c_uint64, u64p, u64p,
                                                 C.POINTER(C.c_int64)]
     L.flate_hip_inflate_stream_reset.argtypes = [vp, vp, C.c_uint64]
-    L.flate_hip_checksum_batch.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint32]
+    if os.environ.get("FLATE_HIP_LIB") is None or hasattr(L, "flate_hip_checksum_batch"):
+        # (a developer's A/B build of an older tree may lack the newest entry point; the product library may not)
+        L.flate_hip_checksum_batch.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint32]
     L.flate_hip_inflate_stream_free.argtypes = [vp]
     L.flate_hip_inflate_stream_free.restype = None
     L.flate_hip_host_register.argtypes = [vp, vp, C.c_size_t]
