@@ -222,10 +222,12 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="skip the exchange step (N>1)")
     ap.add_argument("--gather-mode", default="allgather", choices=["allgather", "sendrecv"],
                     help="exchange inside the timed region: padded all_gather_into_tensor or grouped isend/irecv")
-    ap.add_argument("--native-gather", action="store_true",
-                    help="N>1, nccl: after the timed region also run the exchange through the C ABI "
-                         "(flate_hip_gather_compressed on the library's own RCCL communicator), both forms, "
-                         "checked against the torch.distributed result")
+    ap.add_argument("--native-gather", action="store_true", help="(default since round 5; kept for old command lines)")
+    ap.add_argument("--no-native-gather", action="store_true",
+                    help="N>1: skip the exchange through the C ABI.  By default, after the timed region, every rank "
+                         "also runs flate_hip_gather_compressed on the library's own RCCL communicator, both forms, "
+                         "times them against 7 x 153 GB/s of xGMI and compares the result with torch.distributed's "
+                         "(a mismatch ends the run with an error)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-streams", type=int, default=16384,
                     help="streams of the workload the CPU oracle is timed on (about 10 CPU-seconds per GiB)")
@@ -464,10 +466,12 @@ def bench_deflate(args, env, host, d_in, in_off, n, blen):
                 gather_info[mode + "_error"] = "%s: %s" % (type(e).__name__, e)
                 break
         del side_buf
-        if args.native_gather and env["cuda"] and dist.get_backend() == "nccl":
-            # the same exchange through include/flate_hip.h (what a MoonBit / C++ host calls)
+        native_ok = (env["cuda"] and dist.get_backend() == "nccl") or hasattr(eng, "native_comm")
+        if not args.no_native_gather and native_ok:
+            # the same exchange through include/flate_hip.h (what a MoonBit / C++ host calls): ON by default, so
+            # that the first run on a multi-GPU node exercises flate_hip_gather_* over real RCCL / xGMI
             try:
-                comm = shard.NativeComm(eng, rank, world, dist)
+                comm = eng.native_comm(rank, world, dist) if hasattr(eng, "native_comm") else shard.NativeComm(eng, rank, world, dist)
                 nat = {}
                 for mode in ("allgather", "sendrecv"):
                     ts = []
@@ -479,12 +483,18 @@ def bench_deflate(args, env, host, d_in, in_off, n, blen):
                         ts.append(time.perf_counter() - t1)
                     for j in range(0, world * n, max(1, world * n // 64)):
                         if not torch.equal(ng.stream(j), g.stream(j)):
-                            raise SystemExit("C-ABI exchange differs from torch.distributed at stream %d" % j)
-                    nat[mode + "_ms"] = summarize(ts)
+                            raise SystemExit("PARITY FAILURE: C-ABI exchange (%s) differs from torch.distributed at stream %d" % (mode, j))
+                    ms = summarize(ts)
+                    gbs = recv / (ms["mean"] * 1e-3) / 1e9
+                    nat[mode + "_ms"] = ms
+                    nat[mode + "_GBs"] = round(gbs, 2)
+                    nat[mode + "_frac_of_xgmi"] = round(gbs / XGMI_PEAK_GBS, 4)
+                nat["compared_streams"] = len(range(0, world * n, max(1, world * n // 64)))
                 comm.close()
                 gather_info["c_abi"] = nat
-            except Exception as e:  # noqa: BLE001
+            except Exception as e:  # noqa: BLE001  (a missing RCCL must not cost the run its line; a mismatch does, above)
                 gather_info["c_abi_error"] = "%s: %s" % (type(e).__name__, e)
+                print("bench: C-ABI exchange failed: %s" % gather_info["c_abi_error"], file=sys.stderr)
         mins = [gather_info[m + "_ms"]["min"] for m in ("allgather", "sendrecv") if m + "_ms" in gather_info]
         if mins:
             best = min(mins)
@@ -733,14 +743,20 @@ def extra_legs(args, env):
                 for ck, ref in (("adler32", zlib.adler32), ("crc32", zlib.crc32)):
                     eng.checksum_batch(d_in, in_off, ck)
                     kms = []
+                    cts = []  # the whole call as the caller sees it (staging, launches, the read-back of the sums)
                     for _ in range(5):
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
                         got = eng.checksum_batch(d_in, in_off, ck)
+                        torch.cuda.synchronize()
+                        cts.append(time.perf_counter() - t1)
                         kms.append(eng.last_timing()["checksum"])
                     for i in range(0, n, 512):
                         if int(got[i]) != ref(host[i * blen:(i + 1) * blen].tobytes()):
                             raise SystemExit("checksum %s differs from zlib's at stream %d" % (ck, i))
-                    gbs = n * blen / (min(kms) * 1e-3) / 1e9
+                    gbs = n * blen / (sum(kms) / len(kms) * 1e-3) / 1e9  # from the MEAN, like every other leg
                     sums[ck] = {"kernel_ms": summarize([k * 1e-3 for k in kms]), "GB_per_s": round(gbs, 1),
+                                "call_ms": summarize(cts), "call_GB_per_s": round(n * blen / (sum(cts) / len(cts)) / 1e9, 1),
                                 "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                              "frac": round(gbs / HBM_PEAK_GBS, 4)},
                                 "checked_against_zlib_streams": len(range(0, n, 512))}

@@ -57,13 +57,63 @@ def id_component(build_id, group):
     return None
 
 
-def _stale():
-    if not os.path.exists(LIB_PATH):
+def _stale(lib_path=None):
+    lib_path = lib_path or LIB_PATH
+    if not os.path.exists(lib_path):
         return True
-    t = os.path.getmtime(LIB_PATH)
+    t = os.path.getmtime(lib_path)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + \
            [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+OBJ_DIR = os.path.join(ROOT, "build", "obj")
+# The TEST build: the same objects, except that gather.hip is compiled with -DFLATE_HIP_TEST_BUILD, which is
+# the only thing that lets FLATE_HIP_TEST_TRANSPORT replace RCCL (tests/rehearsal_transport/).  The product
+# library has no such hook; tests that need it load this file through FLATE_HIP_LIB.
+TEST_LIB_PATH = os.path.join(LIB_DIR, "libflate_hip_testbuild.so")
+TEST_BUILD_FLAGS = {"gather.hip": ["-DFLATE_HIP_TEST_BUILD"]}
+
+
+def _compile_objects(hipcc, flags_by_source, verbose):
+    """One object per source, compiled in parallel and cached under build/obj by a hash of the source,
+    the headers and the flags (a kernel experiment recompiles one file, not nine)."""
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hdr_hash = _hash_files([h for h in HEADERS])
+    base = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+    build_id = {"flate_api.hip": ["-DFLATE_HIP_BUILD_ID=\"%s\"" % source_hash()]}  # (the one file that reports it)
+    jobs = []
+    for src in SOURCES:
+        path = os.path.join(CSRC, src)
+        if not os.path.exists(path):
+            continue
+        flags = base + build_id.get(src, []) + flags_by_source.get(src, [])
+        key = hashlib.sha256((hdr_hash + "\0" + " ".join(flags) + "\0").encode() + open(path, "rb").read()).hexdigest()[:16]
+        obj = os.path.join(OBJ_DIR, "%s-%s.o" % (os.path.splitext(src)[0], key))
+        jobs.append((path, obj, flags))
+
+    def one(job):
+        path, obj, flags = job
+        if not os.path.exists(obj):
+            cmd = [hipcc] + flags + ["-c", path, "-o", obj + ".tmp"]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+            os.replace(obj + ".tmp", obj)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        return list(pool.map(one, jobs))
+
+
+def _link(hipcc, objs, out, verbose):
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", out + ".tmp", "-lpthread", "-ldl"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    os.replace(out + ".tmp", out)
 
 
 def build(force=False, verbose=False):
@@ -71,15 +121,22 @@ def build(force=False, verbose=False):
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
-           "-DFLATE_HIP_BUILD_ID=\"%s\"" % source_hash(),
-           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + srcs + ["-o", LIB_PATH, "-lpthread", "-ldl"]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+    _link(hipcc, _compile_objects(hipcc, {}, verbose), LIB_PATH, verbose)
     return LIB_PATH
+
+
+def build_test(force=False, verbose=False):
+    """libflate_hip_testbuild.so: see TEST_LIB_PATH.  Test infrastructure, built by the tests that need it
+    (and by __graft_entry__.build(), so that it travels to the GPU box)."""
+    if not force and not _stale(TEST_LIB_PATH):
+        return TEST_LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    _link(hipcc, _compile_objects(hipcc, TEST_BUILD_FLAGS, verbose), TEST_LIB_PATH, verbose)
+    return TEST_LIB_PATH
 
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--test" in sys.argv:
+        print(build_test(force="--force" in sys.argv, verbose=True))

@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <new>
+#include <stdexcept>
 #include <vector>
 
 #include <string>
@@ -295,14 +297,6 @@ __global__ __launch_bounds__(256) void checksum_fold_kernel(FoldParams P) {
   }
 }
 
-struct Dev {
-  void *p = nullptr;
-  ~Dev() {
-    if (p) (void)hipFree(p);
-  }
-  int get(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16) == hipSuccess ? 0 : 1; }
-};
-
 }  // namespace
 
 }  // namespace flate
@@ -325,7 +319,8 @@ extern "C" int flate_hip_checksum_batch(flate_hip_ctx *c, const uint8_t *in, con
   };
   if (hipSetDevice(ctx_device(c)) != hipSuccess) return hip_fail("hipSetDevice");
   hipStream_t st = ctx_stream(c);
-  // pieces
+  // pieces.  (The vectors may throw: nothing may cross the extern "C" boundary -- see the catch at the end.)
+  try {
   std::vector<uint64_t> poff;
   std::vector<uint32_t> plen, pbase(n + 1, 0);
   for (uint32_t i = 0; i < n; ++i) {
@@ -339,18 +334,35 @@ extern "C" int flate_hip_checksum_batch(flate_hip_ctx *c, const uint8_t *in, con
   pbase[n] = (uint32_t)plen.size();
   const uint32_t np = (uint32_t)plen.size();
   const bool dev = (flags & FLATE_HIP_DEVICE_PTRS) != 0;
-  Dev d_in, d_poff, d_plen, d_pbase, d_ioff, d_crc, d_asum, d_wsum, d_out;
-  if (d_poff.get((size_t)np * 8) || d_plen.get((size_t)np * 4) || d_pbase.get(((size_t)n + 1) * 4) ||
-      d_ioff.get(((size_t)n + 1) * 8) || d_crc.get((size_t)np * 4) || d_asum.get((size_t)np * 4) ||
-      d_wsum.get((size_t)np * 8) || d_out.get((size_t)n * 4) || (!dev && d_in.get(total + 16)))
-    return hip_fail("hipMalloc (checksum scratch)");
-  auto up = [&](void *dst, const void *src, size_t bytes) {
-    return !bytes || hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st) == hipSuccess;
-  };
-  if (!up(d_poff.p, poff.data(), (size_t)np * 8) || !up(d_plen.p, plen.data(), (size_t)np * 4) ||
-      !up(d_pbase.p, pbase.data(), ((size_t)n + 1) * 4) || !up(d_ioff.p, in_off, ((size_t)n + 1) * 8) ||
-      (!dev && !up(d_in.p, in, total)))
-    return hip_fail("hipMemcpyAsync (checksum input)");
+  // one grow-only scratch of the ctx, carved into the call's arrays (round 4 did nine hipMalloc / hipFree
+  // pairs per call: hipFree drains the whole device, i.e. every other context and the host pipelines' lanes)
+  struct Dev { void *p = nullptr; } d_in, d_poff, d_plen, d_pbase, d_ioff, d_crc, d_asum, d_wsum, d_out;
+  {
+    size_t at = 0;
+    auto carve = [&](size_t bytes) { const size_t o = at; at += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_poff = carve((size_t)np * 8), o_wsum = carve((size_t)np * 8), o_ioff = carve(((size_t)n + 1) * 8),
+                 o_plen = carve((size_t)np * 4 + 4), o_pbase = carve(((size_t)n + 1) * 4 + 4), o_crc = carve((size_t)np * 4),
+                 o_asum = carve((size_t)np * 4), o_out = carve((size_t)n * 4 + 4);
+    void *base = nullptr;
+    int rc = ctx_scratch(c, 0, at, &base);
+    if (rc == FLATE_HIP_OK && !dev) rc = ctx_scratch(c, 1, total + 16, &d_in.p);
+    if (rc != FLATE_HIP_OK) return rc;
+    uint8_t *b8 = (uint8_t *)base;
+    d_poff.p = b8 + o_poff, d_wsum.p = b8 + o_wsum, d_ioff.p = b8 + o_ioff, d_plen.p = b8 + o_plen;
+    d_pbase.p = b8 + o_pbase, d_crc.p = b8 + o_crc, d_asum.p = b8 + o_asum, d_out.p = b8 + o_out;
+  }
+  // the index arrays travel through the ctx's pinned staging and its copy kernel, not through DMA
+  // commands that queue behind whatever bulk copy another thread has in flight (flate_api.hip: ctl_up)
+  {
+    int rc = ctx_ctl_begin(c, (size_t)np * 12 + ((size_t)n + 1) * 12 + 4 * 512, (size_t)n * 4 + 512);
+    if (rc == FLATE_HIP_OK) rc = ctx_ctl_up(c, d_poff.p, poff.data(), (size_t)np * 8);
+    if (rc == FLATE_HIP_OK) rc = ctx_ctl_up(c, d_plen.p, plen.data(), (size_t)np * 4);
+    if (rc == FLATE_HIP_OK) rc = ctx_ctl_up(c, d_pbase.p, pbase.data(), ((size_t)n + 1) * 4);
+    if (rc == FLATE_HIP_OK) rc = ctx_ctl_up(c, d_ioff.p, in_off, ((size_t)n + 1) * 8);
+    if (rc != FLATE_HIP_OK) return rc;
+    if (!dev && total && hipMemcpyAsync(d_in.p, in, total, hipMemcpyHostToDevice, st) != hipSuccess)
+      return hip_fail("hipMemcpyAsync (checksum input)");
+  }
   const X2n x2n = make_x2n();
   if (np) {
     PieceParams P{};
@@ -388,8 +400,18 @@ extern "C" int flate_hip_checksum_batch(flate_hip_ctx *c, const uint8_t *in, con
   hipLaunchKernelGGL(checksum_fold_kernel, dim3((n + 3) / 4), dim3(256), 0, st, F);
   ctx_stage_end(c, FLATE_HIP_STAGE_CHECKSUM);
   if (hipGetLastError() != hipSuccess) return hip_fail("checksum kernels");
-  if (hipMemcpyAsync(out, d_out.p, (size_t)n * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
-      hipStreamSynchronize(st) != hipSuccess)
-    return hip_fail("checksum read-back");
+  {
+    const int rc = ctx_ctl_down(c, out, d_out.p, (size_t)n * 4);
+    if (rc != FLATE_HIP_OK) return rc;
+  }
+  if (hipStreamSynchronize(st) != hipSuccess) return hip_fail("checksum read-back");
+  ctx_ctl_finish(c);
   return ctx_stage_collect(c, FLATE_HIP_STAGE_CHECKSUM);
+  } catch (const std::bad_alloc &) {
+    ctx_set_error(c, "out of host memory (checksum piece index)");
+    return FLATE_HIP_E_HIP;
+  } catch (const std::exception &e) {
+    ctx_set_error(c, e.what());
+    return FLATE_HIP_E_INTERNAL;
+  }
 }

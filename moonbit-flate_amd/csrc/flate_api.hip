@@ -14,6 +14,7 @@
 #include <cstring>
 #include <condition_variable>
 #include <exception>
+#include <stdexcept>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -80,6 +81,7 @@ struct flate_hip_ctx {
   // window-granular scheduling of multi-window streams (lz77_kernels.hip, uq_*): on by default
   int window_units = 1;
   DevBuf d_uq_ready, d_uq_tables, d_uq_sweep;
+  DevBuf d_aux[2];  // ctx_scratch (checksum.hip)
   // measurement aids (flate_hip_last_resident_share, option "profile_split_streams")
   uint32_t profile_split = 0;        // > 0: LDS-table blocks take exactly the first K queue entries,
                                      // the guest blocks the rest (two queues instead of one)
@@ -227,6 +229,21 @@ void ctl_finish(flate_hip_ctx *c) {
   for (const auto &p : c->ctl_pending) memcpy(p.host_dst, c->ctl_down_buf.p + p.off, p.bytes);
   c->ctl_pending.clear();
 }
+
+}  // namespace
+namespace flate {
+int ctx_scratch(flate_hip_ctx *c, int slot, size_t bytes, void **p) {
+  if (slot < 0 || slot > 1) return FLATE_HIP_E_INVALID;
+  const int rc = ensure(c, c->d_aux[slot], bytes + 16);
+  *p = c->d_aux[slot].p;
+  return rc;
+}
+int ctx_ctl_begin(flate_hip_ctx *c, size_t up_bytes, size_t down_bytes) { return ctl_begin(c, up_bytes, down_bytes); }
+int ctx_ctl_up(flate_hip_ctx *c, void *dev_dst, const void *host_src, size_t bytes) { return ctl_up(c, dev_dst, host_src, bytes); }
+int ctx_ctl_down(flate_hip_ctx *c, void *host_dst, const void *dev_src, size_t bytes) { return ctl_down(c, host_dst, dev_src, bytes); }
+void ctx_ctl_finish(flate_hip_ctx *c) { ctl_finish(c); }
+}  // namespace flate
+namespace {
 
 // Probe offsets of the skip heuristic (deflate-fast.mbt:178-187) from skip = 32.
 std::vector<uint16_t> make_scan_table() {
@@ -604,6 +621,8 @@ void flate_hip_destroy(flate_hip_ctx *c) {
   release(c->d_uq_ready);
   release(c->d_uq_tables);
   release(c->d_uq_sweep);
+  release(c->d_aux[0]);
+  release(c->d_aux[1]);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -1079,6 +1098,7 @@ static int deflate_host_pipelined(flate_hip_ctx *c, const uint8_t *in, const uin
     std::vector<uint64_t> off;
     int rc = FLATE_HIP_OK;
     bool done = false;
+    bool threw = false;  // an exception was caught in the lane's thread
     float stage[FLATE_HIP_STAGE_COUNT] = {0, 0, 0, 0};
     std::string err;
   };
@@ -1095,20 +1115,35 @@ static int deflate_host_pipelined(flate_hip_ctx *c, const uint8_t *in, const uin
         std::lock_guard<std::mutex> l(mu);
         if (stop) r.rc = FLATE_HIP_E_INTERNAL;
       }
-      if (r.rc == FLATE_HIP_OK && !pipe.wait_in(g)) r.rc = FLATE_HIP_E_HIP;
-      const uint32_t cnt = lo[g + 1] - lo[g];
-      r.off.assign((size_t)cnt + 1, 0);
-      if (r.rc == FLATE_HIP_OK && cnt) {
-        gin.resize((size_t)cnt + 1);
-        const uint64_t base = in_off[lo[g]];
-        for (uint32_t i = 0; i <= cnt; ++i) gin[i] = in_off[lo[g] + i] - base;
-        lc->hip_err.clear();
-        const double a = host_now_ms();
-        r.rc = deflate_common(lc, d_in + base, gin.data(), cnt, d_out + slot[g], slot[g + 1] - slot[g], r.off.data(),
-                              flags | FLATE_HIP_DEVICE_PTRS, false, nullptr);
-        host_trace(t_call, "compute", g, a, host_now_ms());
-        for (int s = 0; s < FLATE_HIP_STAGE_COUNT; ++s) r.stage[s] = lc->stage_ms[s];
-        if (r.rc != FLATE_HIP_OK) r.err = lc->hip_err;
+      // (this is a worker thread: an exception that left it would end the process.  std::bad_alloc /
+      // length_error from the vectors here or inside deflate_common are recorded instead; the calling thread
+      // rethrows after the join, and its caller runs the batch as one pass, as before the lanes existed)
+      try {
+        if (r.rc == FLATE_HIP_OK && !pipe.wait_in(g)) r.rc = FLATE_HIP_E_HIP;
+        const uint32_t cnt = lo[g + 1] - lo[g];
+        r.off.assign((size_t)cnt + 1, 0);
+        if (r.rc == FLATE_HIP_OK && cnt) {
+          gin.resize((size_t)cnt + 1);
+          const uint64_t base = in_off[lo[g]];
+          for (uint32_t i = 0; i <= cnt; ++i) gin[i] = in_off[lo[g] + i] - base;
+          lc->hip_err.clear();
+          const double a = host_now_ms();
+          r.rc = deflate_common(lc, d_in + base, gin.data(), cnt, d_out + slot[g], slot[g + 1] - slot[g], r.off.data(),
+                                flags | FLATE_HIP_DEVICE_PTRS, false, nullptr);
+          host_trace(t_call, "compute", g, a, host_now_ms());
+          for (int s = 0; s < FLATE_HIP_STAGE_COUNT; ++s) r.stage[s] = lc->stage_ms[s];
+          if (r.rc != FLATE_HIP_OK) r.err = lc->hip_err;
+        }
+      } catch (const std::exception &e) {
+        r.rc = FLATE_HIP_E_INTERNAL;
+        r.threw = true;
+        try {
+          r.err = std::string("host pipeline lane: ") + e.what();
+        } catch (...) {
+        }
+      } catch (...) {
+        r.rc = FLATE_HIP_E_INTERNAL;
+        r.threw = true;
       }
       std::lock_guard<std::mutex> l(mu);
       r.done = true;
@@ -1134,6 +1169,7 @@ static int deflate_host_pipelined(flate_hip_ctx *c, const uint8_t *in, const uin
 
   float stage_sum[FLATE_HIP_STAGE_COUNT] = {0, 0, 0, 0};
   uint64_t at = 0;
+  bool lane_threw = false;
   rc = FLATE_HIP_OK;
   out_off[0] = 0;
   for (uint32_t g = 0; g < G && rc == FLATE_HIP_OK; ++g) {
@@ -1144,6 +1180,7 @@ static int deflate_host_pipelined(flate_hip_ctx *c, const uint8_t *in, const uin
     }
     if (r.rc != FLATE_HIP_OK) {
       rc = r.rc;
+      lane_threw = r.threw;
       if (c->hip_err.empty()) c->hip_err = r.err;
       break;
     }
@@ -1165,6 +1202,7 @@ static int deflate_host_pipelined(flate_hip_ctx *c, const uint8_t *in, const uin
   for (auto &w : workers)
     if (w.joinable()) w.join();
   const std::string err = pipe.finish();
+  if (lane_threw) throw std::runtime_error(c->hip_err);  // every thread has ended: the caller falls back to one pass
   if (rc == FLATE_HIP_OK && !err.empty()) rc = FLATE_HIP_E_HIP;
   if (rc == FLATE_HIP_E_HIP && c->hip_err.empty()) c->hip_err = err;
   for (int k = 0; k < FLATE_HIP_STAGE_COUNT; ++k) c->stage_ms[k] = stage_sum[k];

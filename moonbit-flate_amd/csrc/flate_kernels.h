@@ -199,4 +199,13 @@ uint32_t ctx_num_cus(flate_hip_ctx *c);
 void ctx_stage_begin(flate_hip_ctx *c, int stage);
 void ctx_stage_end(flate_hip_ctx *c, int stage);
 int ctx_stage_collect(flate_hip_ctx *c, int stage);
+// grow-only device scratch owned by the ctx (slot 0: a call's index arrays and partial results, slot 1: a
+// staged copy of host input): no hipMalloc / hipFree per call -- hipFree drains the whole device
+int ctx_scratch(flate_hip_ctx *c, int slot, size_t bytes, void **p);
+// the ctx's pinned staging + copy kernel for small index arrays (see ctl_begin in flate_api.hip);
+// ctx_ctl_finish after the stream has been synchronised
+int ctx_ctl_begin(flate_hip_ctx *c, size_t up_bytes, size_t down_bytes);
+int ctx_ctl_up(flate_hip_ctx *c, void *dev_dst, const void *host_src, size_t bytes);
+int ctx_ctl_down(flate_hip_ctx *c, void *host_dst, const void *dev_src, size_t bytes);
+void ctx_ctl_finish(flate_hip_ctx *c);
 }  // namespace flate

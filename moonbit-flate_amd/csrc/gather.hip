@@ -47,10 +47,12 @@ Rccl *rccl() {
   static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
+#ifdef FLATE_HIP_TEST_BUILD
+    // TEST BUILD ONLY (moonbit-flate_amd/build.py: build_test -> libflate_hip_testbuild.so; the product
+    // library is compiled without this block and binds RCCL and nothing else).
     // FLATE_HIP_TEST_TRANSPORT = path of a library with the same nine entry points: the tests'
     // rehearsal transport (tests/rehearsal_transport/, ranks as processes on ONE GPU exchanging
     // through host shared memory), so that the multi-rank branches below can run on a one-GPU box.
-    // It is never part of this library.
     if (const char *alt = getenv("FLATE_HIP_TEST_TRANSPORT")) {
       r.h = dlopen(alt, RTLD_NOW | RTLD_LOCAL);
       if (!r.h) {
@@ -58,6 +60,7 @@ Rccl *rccl() {
         return;
       }
     }
+#endif
     for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
       if (r.h) break;
       r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);

@@ -41,3 +41,47 @@ class OracleEngine:
 
     def close(self):
         pass
+
+    def native_comm(self, rank, world, dist):
+        """Stand-in for shard.NativeComm (the C-ABI exchange needs a GPU): the same interface over
+        torch.distributed, so that bench.py's DEFAULT N > 1 path -- exchange through the C ABI after the timed
+        region, compared with the torch.distributed result -- is rehearsed on CPU."""
+        return _RehearsalComm(rank, world, dist)
+
+
+class _Gathered:
+    def __init__(self, buf, off, length):
+        self.buf, self.off, self.length = buf, off, length
+
+    def stream(self, j):
+        o = int(self.off[j])
+        return self.buf[o:o + int(self.length[j])]
+
+
+class _RehearsalComm:
+    def __init__(self, rank, world, dist):
+        self.rank, self.world, self.dist = rank, world, dist
+
+    def gather(self, local_buf, local_off, mode="allgather"):
+        import torch
+        local_off = np.ascontiguousarray(local_off, dtype=np.int64)
+        k, nbytes = local_off.size - 1, int(local_off[-1])
+        meta = [None] * self.world
+        self.dist.all_gather_object(meta, (nbytes, local_off.tolist()))
+        pad = (max(m[0] for m in meta) + 4095) // 4096 * 4096
+        mine = torch.zeros(pad, dtype=torch.uint8)
+        mine[:nbytes] = local_buf[:nbytes]
+        parts = [torch.empty(pad, dtype=torch.uint8) for _ in range(self.world)]
+        self.dist.all_gather(parts, mine)
+        offs, lens, chunks, base = [], [], [], 0
+        for r, (nb, lo) in enumerate(meta):
+            # allgather: rank r's shard at r * pad; sendrecv: the shards back to back (flate_hip.h)
+            start = r * pad if mode == "allgather" else base
+            chunks.append(parts[r] if mode == "allgather" else parts[r][:nb])
+            offs += [start + lo[i] for i in range(len(lo) - 1)]
+            lens += [lo[i + 1] - lo[i] for i in range(len(lo) - 1)]
+            base += nb
+        return _Gathered(torch.cat(chunks), np.array(offs, np.uint64), np.array(lens, np.uint64))
+
+    def close(self):
+        pass

@@ -119,6 +119,27 @@ def test_bench_spawns_its_own_ranks_and_verifies_the_gathered_buffer():
     g = line["config"]["gather"]
     assert g["allgather_ms"]["min"] > 0 and g["sendrecv_ms"]["min"] > 0 and g["bytes_received_per_gpu"] > 0
     assert line["cpu_baseline"]["value"] > 0 and "TEST-ENGINE" in line["data"]
+    # the exchange through the C ABI is part of the DEFAULT N > 1 run (here: the test engine's stand-in for it):
+    # both forms timed, priced against xGMI, compared with the torch.distributed result
+    c = g["c_abi"]
+    assert c["allgather_ms"]["mean"] > 0 and c["sendrecv_ms"]["mean"] > 0 and c["compared_streams"] >= 64
+    assert "allgather_frac_of_xgmi" in c and "c_abi_error" not in g
+
+
+def test_bench_without_the_c_abi_exchange_when_asked():
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["FLATE_BENCH_TEST_ENGINE"] = "tests.cpu_engine:OracleEngine"
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--streams", "64", "--stream-len", "4096", "--no-native-gather"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    g = json.loads(r.stdout.strip().splitlines()[-1])["config"]["gather"]
+    assert "c_abi" not in g and "c_abi_error" not in g
 
 
 def test_bench_rejects_a_world_size_that_contradicts_gpus():

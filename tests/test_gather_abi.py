@@ -158,13 +158,24 @@ def test_rehearsal_transport_builds_and_exports_what_gather_binds():
         assert hasattr(L, name), name
 
 
+def test_the_product_library_has_no_transport_hook():
+    """FLATE_HIP_TEST_TRANSPORT is honoured by the test build only (csrc/gather.hip, -DFLATE_HIP_TEST_BUILD):
+    the library that ships must not even contain the variable's name."""
+    build = importlib.import_module("moonbit-flate_amd.build")
+    assert b"FLATE_HIP_TEST_TRANSPORT" not in open(build.build(), "rb").read()
+    assert b"FLATE_HIP_TEST_TRANSPORT" in open(build.build_test(), "rb").read()
+
+
 @pytest.mark.gpu
 def test_two_ranks_through_the_c_abi_exchange_on_one_card():
     """tests/tools/native_gather_ranks.py with two processes: both exchange forms, the overlapped pair,
     a pad overflow and a stream-count overflow (E_AGAIN on both ranks, plans raised alike), an `out` that
     is too small on one rank (E_OUT_TOO_SMALL on both), every gathered stream checked against the oracle."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, FLATE_HIP_TEST_TRANSPORT=_rehearsal_transport(), FLATE_REHEARSAL_TIMEOUT_S="90")
+    # the hook that lets a transport replace RCCL exists in the TEST build of the library only
+    test_lib = importlib.import_module("moonbit-flate_amd.build").build_test()
+    env = dict(os.environ, FLATE_HIP_TEST_TRANSPORT=_rehearsal_transport(), FLATE_REHEARSAL_TIMEOUT_S="90",
+               FLATE_HIP_LIB=test_lib)
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     out = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "native_gather_ranks.py"), "2"],
@@ -181,7 +192,7 @@ def test_two_ranks_over_rccl_when_the_box_has_two_gpus():
         pytest.skip("needs two GPUs")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
-    for k in ("WORLD_SIZE", "RANK", "FLATE_HIP_TEST_TRANSPORT"):
+    for k in ("WORLD_SIZE", "RANK", "FLATE_HIP_TEST_TRANSPORT", "FLATE_HIP_LIB"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "native_gather_ranks.py"), "2"],
                          env=env, capture_output=True, text=True, timeout=600)

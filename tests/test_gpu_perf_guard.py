@@ -1,14 +1,23 @@
-"""Loose timing floors that catch STRUCTURAL slowdowns, not percent-level ones: the match finder is two kernels
+"""Timing guards that catch STRUCTURAL slowdowns, not percent-level ones: the match finder is two kernels
 that must run side by side, and the host-pointer pipelines' copies must run beside the kernels.  When two of
 those streams shared a HIP hardware queue (profiles/r04/README.md section 4) a lane's match finder took 27.9 ms
-per GiB instead of 19.6 and nothing but a bench line showed it.  The bounds sit 20 % above what the slowest box
-of the pool measured."""
+per GiB instead of 19.6 and nothing but a bench line showed it.
+Every bound is a RATIO to a calibration launch on the same box in the same test (the boxes of the pool spread
+by 8 %, and a slower one must not turn a guard into a red run): no absolute milliseconds."""
 import numpy as np
 import pytest
 
 from util import flate
 
 pytestmark = pytest.mark.gpu
+
+
+def _best_lz77_ms(eng, run, reps):
+    best = 1e9
+    for _ in range(reps):
+        run()
+        best = min(best, eng.last_timing()["lz77_match"])
+    return best
 
 
 def test_match_finder_kernels_run_side_by_side_in_small_launches():
@@ -20,34 +29,40 @@ def test_match_finder_kernels_run_side_by_side_in_small_launches():
         d = torch.from_numpy(flate.synth("text", n, blen)).cuda()
         off = flate.uniform_offsets(n, blen)
         out = torch.empty(n * blen + (n * blen >> 3) + 4096, dtype=torch.uint8, device="cuda")
-        best = 1e9
-        for _ in range(4):
-            eng.deflate_batch(d, off, out=out)
-            best = min(best, eng.last_timing()["lz77_match"])
-        # 4.9 ms measured (the two kernels serialised: ~8)
-        assert best < 6.5, "match finder of a 4096-stream launch: %.2f ms" % best
+        both = _best_lz77_ms(eng, lambda: eng.deflate_batch(d, off, out=out), 4)
+        # calibration: the LDS-table kernel alone on the same batch
+        eng.set_option("guest_blocks", 0)
+        alone = _best_lz77_ms(eng, lambda: eng.deflate_batch(d, off, out=out), 3)
+        # measured: 4.9 ms beside the guests against 7.1 alone (0.69); the two kernels one after the other
+        # would take longer than the LDS-table kernel alone (> 1.1)
+        assert both < 0.9 * alone, "match finder of a 4096-stream launch: %.2f ms with guests, %.2f ms without" % (both, alone)
     finally:
         eng.close()
 
 
 def test_a_lanes_match_finder_keeps_its_pace_inside_the_host_pipeline():
-    n, blen = 16384, 65536
+    import torch
+    n, blen, groups = 16384, 65536, 4
     host = flate.synth("text", n, blen)
     off = flate.uniform_offsets(n, blen)
     h_out = np.empty(n * blen + (n * blen >> 3) + 4096, dtype=np.uint8)
     eng = flate.FlateEngine(0)
     try:
         eng.set_profiling(True)
+        # calibration: one group's worth of streams, resident on the device, as its own launch
+        ng = n // groups
+        d = torch.from_numpy(host[:ng * blen]).cuda()
+        d_out = torch.empty(ng * blen + (ng * blen >> 3) + 4096, dtype=torch.uint8, device="cuda")
+        one_group = _best_lz77_ms(eng, lambda: eng.deflate_batch(d, off[:ng + 1], out=d_out), 4)
+        del d, d_out
         eng.set_option("host_pipeline_lanes", 1)
-        eng.set_option("host_pipeline_groups", 4)
-        eng.set_option("host_pipeline_group_streams", 4096)
+        eng.set_option("host_pipeline_groups", groups)
+        eng.set_option("host_pipeline_group_streams", ng)
         with eng.host_register(host), eng.host_register(h_out):
-            best = 1e9
-            for _ in range(3):
-                eng.deflate_batch(host, off, out=h_out)
-                best = min(best, eng.last_timing()["lz77_match"])
-        # the groups' match-finder launches summed: 19.4-19.8 ms measured; 27.9 when a lane's guest stream had
-        # landed on its kernel stream's hardware queue
-        assert best < 24.0, "match finder inside the host pipeline: %.1f ms per GiB" % best
+            piped = _best_lz77_ms(eng, lambda: eng.deflate_batch(host, off, out=h_out), 3)
+        # the groups' match-finder launches summed: 19.4-19.8 ms measured = 4 x 4.9; 27.9 (1.42 x) when a lane's
+        # guest stream had landed on its kernel stream's hardware queue
+        assert piped < 1.2 * groups * one_group, \
+            "match finder inside the host pipeline: %.1f ms per GiB against %d x %.2f ms for its groups alone" % (piped, groups, one_group)
     finally:
         eng.close()
