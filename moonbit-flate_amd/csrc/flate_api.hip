@@ -60,6 +60,7 @@ struct flate_hip_ctx {
   uint64_t h_total_bytes = 0;
   uint32_t num_cus = 256;
   int inflate_lanes = 0;  // streams per wavefront of that inflater: 0 = by batch size, or 16/32/64
+  int inflate_row = 8;    // dwords of a lane's output row in the 64-lane form (0 = stores go straight to memory, 8, 16)
   // batches at least this large use the lane-per-stream inflater: it takes ~30 ms for 64 KiB
   // streams whatever the batch size, the wave-per-stream one ~13 ms per 1024 streams (measured:
   // tools/inflate_crossover.py)
@@ -644,6 +645,8 @@ int flate_hip_set_option(flate_hip_ctx *c, const char *name, int64_t value) {
     c->guest_min = (uint32_t)value;
   } else if (k == "inflate_lanes" && (value == 0 || value == 16 || value == 32 || value == 64)) {
     c->inflate_lanes = (int)value;
+  } else if (k == "inflate_row_dwords" && (value == 0 || value == 8 || value == 16)) {
+    c->inflate_row = (int)value;
   } else if (k == "inflate_simt_min_streams" && value >= 0) {
     c->inflate_simt_min = (uint32_t)value;
   } else if (k == "inflate_spec" && value >= 0 && value <= 2) {
@@ -1738,12 +1741,18 @@ static int inflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
       for (uint32_t b0 = 0; b0 < sblocks; b0 += per) {
         const uint32_t nb = sblocks - b0 < per ? sblocks - b0 : per;
         I.sid0 = b0 * (uint32_t)lpw;
-        if (lpw == 64)
-          hipLaunchKernelGGL(inflate_simt_kernel<64>, dim3(nb), dim3(64), inflate_simt_lds_bytes(64), c->stream, I);
+        // (the output row -- a lane's output collected in registers and stored as whole aligned pieces -- pays
+        // where the chip is full of lanes: the 64-lane form only)
+        if (lpw == 64 && c->inflate_row == 16)
+          hipLaunchKernelGGL((inflate_simt_kernel<64, 16>), dim3(nb), dim3(64), inflate_simt_lds_bytes(64), c->stream, I);
+        else if (lpw == 64 && c->inflate_row == 8)
+          hipLaunchKernelGGL((inflate_simt_kernel<64, 8>), dim3(nb), dim3(64), inflate_simt_lds_bytes(64), c->stream, I);
+        else if (lpw == 64)
+          hipLaunchKernelGGL((inflate_simt_kernel<64, 0>), dim3(nb), dim3(64), inflate_simt_lds_bytes(64), c->stream, I);
         else if (lpw == 32)
-          hipLaunchKernelGGL(inflate_simt_kernel<32>, dim3(nb), dim3(64), inflate_simt_lds_bytes(32), c->stream, I);
+          hipLaunchKernelGGL((inflate_simt_kernel<32, 0>), dim3(nb), dim3(64), inflate_simt_lds_bytes(32), c->stream, I);
         else
-          hipLaunchKernelGGL(inflate_simt_kernel<16>, dim3(nb), dim3(64), inflate_simt_lds_bytes(16), c->stream, I);
+          hipLaunchKernelGGL((inflate_simt_kernel<16, 0>), dim3(nb), dim3(64), inflate_simt_lds_bytes(16), c->stream, I);
       }
     }
     else

@@ -152,7 +152,7 @@ __global__ void inflate_spec_kernel(InfParams P);
 #ifndef FLATE_SPEC_LARGE
 #define FLATE_SPEC_LARGE 224, 47, 512  // 19.9 KiB of LDS: two wavefronts per SIMD
 #endif
-template <int LPW>
+template <int LPW, int ROWD>  // ROWD: dwords of the lane's output row (0 = none), see inflate_kernels.hip
 __global__ void inflate_simt_kernel(InfParams P);
 // one long stream decoded in pieces (inflate_stream_kernel.inc): the decoder's state -- the 32 KiB
 // window, the tables of the block in progress, the bit carry, a copy that did not fit -- rests in

@@ -479,6 +479,9 @@ FLATE_D uint2 load_rec(const Walker &w, uint32_t mp, int lane) {
   return r;
 }
 FLATE_D uint32_t load_bytes4(const Walker &w, int pos) {
+#ifdef FLATE_EXP_NO_INPUT  // TIMING EXPERIMENT ONLY (wrong bytes on purpose): the entropy kernels without their reads of the input
+  return 0x20746165u + 0x01010101u * (((uint32_t)pos * 2654435761u) >> 30);
+#endif
   if (pos + 4 <= w.n) {
     uint32_t v;
     __builtin_memcpy(&v, w.src + pos, 4);

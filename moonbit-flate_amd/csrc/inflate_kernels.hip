@@ -893,13 +893,74 @@ FLATE_D int shuff_sym(SBits &b, const DistRegs &D, int dmin, const Limits &lim, 
 }
 
 
+
+// ---- the output ROW of a lane (round 5) ---------------------------------------------------------------
+// Every lane stores into its own stream: a lane-store is its own cache line, and with 65536 streams in
+// flight L2 cannot keep their half-written lines (8 MiB per XCD), so every 8- or 16-byte store left L2
+// as its own sector: 70 GB written for 8.6 GB of output (profiles/r04/inflate_traffic.json).  With
+// ROWD > 0 a lane collects its output in ROWD registers -- bytes [rbase, rbase + 4 ROWD) of its slot, rbase
+// a multiple of 4 ROWD -- and stores a row when it is full: whole aligned pieces, written once.
+// Everything is indexed statically (a dynamic register index would put the lane's state into scratch
+// memory): the bytes of a step -- the copy chunk, then the literals -- are joined in six registers, shifted
+// to the row's byte offset by one v_perm per dword and to its dword offset by a barrel shifter of
+// log2(ROWD) select stages, and OR-ed into the row (whose bytes at and behind the write position are zero).
+
+// keep the first k (0..16) bytes of the 16 in d[0..3]
+FLATE_D void row_keep_first(uint32_t (&d)[4], uint32_t k) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int t = (int)k - 4 * j;
+    const uint32_t nb = (uint32_t)(t < 0 ? 0 : (t > 4 ? 4 : t));
+    const uint32_t m = nb >= 4u ? 0xffffffffu : ((1u << (8u * nb)) - 1u);
+    d[j] &= m;
+  }
+}
+// x shifted left by s (0..3) bytes, the bytes of `below` coming in from underneath
+FLATE_D uint32_t row_shl_bytes(uint32_t x, uint32_t below, uint32_t sel) { return __builtin_amdgcn_perm(x, below, sel); }
+// a[0..5] |= the literals (lo, hi; zero beyond their count) at byte offset k (0..16)
+FLATE_D void row_join(uint32_t (&a)[6], uint32_t lo, uint32_t hi, uint32_t k) {
+  const uint32_t sel = 0x07060504u - 0x01010101u * (k & 3u);
+  const uint32_t l0 = row_shl_bytes(lo, 0u, sel), l1 = row_shl_bytes(hi, lo, sel), l2 = row_shl_bytes(0u, hi, sel);
+  const uint32_t q = k >> 2;  // 0..4 (4 only with k == 16: l2 == 0 then)
+  const bool q0 = q == 0u, q1 = q == 1u, q2 = q == 2u, q3 = q == 3u, q4 = q == 4u;
+  a[0] |= q0 ? l0 : 0u;
+  a[1] |= q1 ? l0 : (q0 ? l1 : 0u);
+  a[2] |= q2 ? l0 : (q1 ? l1 : (q0 ? l2 : 0u));
+  a[3] |= q3 ? l0 : (q2 ? l1 : (q1 ? l2 : 0u));
+  a[4] |= q4 ? l0 : (q3 ? l1 : (q2 ? l2 : 0u));
+  a[5] |= q4 ? l1 : (q3 ? l2 : 0u);
+}
+// f[0 .. ROWD + 6) = the 24 bytes of a[0..5] at byte offset o (0 .. 4 ROWD - 1), zero elsewhere
+template <int ROWD>
+FLATE_D void row_place(uint32_t (&f)[ROWD + 6], const uint32_t (&a)[6], uint32_t o) {
+  constexpr int F = ROWD + 6;
+  const uint32_t sel = 0x07060504u - 0x01010101u * (o & 3u);
+  uint32_t v[F];
+#pragma unroll
+  for (int j = 0; j < F; ++j) {
+    const uint32_t x = j < 6 ? a[j] : 0u, below = (j >= 1 && j <= 6) ? a[j - 1] : 0u;
+    v[j] = j <= 6 ? row_shl_bytes(x, below, sel) : 0u;
+  }
+  const uint32_t q = o >> 2;
+#pragma unroll
+  for (int bit = 1, live = 7; bit < ROWD; bit <<= 1) {  // live = entries that can be non-zero so far
+    const bool on = (q & (uint32_t)bit) != 0u;
+    live = live + bit < F ? live + bit : F;
+#pragma unroll
+    for (int j = F - 1; j >= 0; --j)
+      if (j < live) v[j] = on ? (j >= bit ? v[j - bit] : 0u) : v[j];
+  }
+#pragma unroll
+  for (int j = 0; j < F; ++j) f[j] = v[j];
+}
+
 extern __shared__ uint16_t simt_lds[];  // kLaneWords * LPW entries
 
 }  // namespace
 
 // LPW = streams (active lanes) per wavefront; eight 64-lane wavefronts fit the LDS of a CU, and a
 // batch too small to give every SIMD one of those runs with 32 or 16 lanes per wavefront.
-template <int LPW>
+template <int LPW, int ROWD>
 __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
   const int lane = threadIdx.x;
   const int lds_lane = lane < LPW ? lane : 0;
@@ -926,6 +987,39 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
   uint32_t pend_lo, pend_hi, pend_2 = 0, pend_3 = 0;
   constexpr uint32_t kChunk = 16;
   uint32_t lit_lo, lit_hi, lit_n; // up to eight literals decoded but not stored yet (they end at opos)
+  // ROWD > 0: the output row (see row_place).  Bytes [rbase, wpos) of the output are in row[], not in memory
+  // yet; wpos = opos minus the literals still in lit_lo / lit_hi.
+  constexpr int RD = ROWD > 0 ? ROWD : 1;
+  uint32_t row[RD];
+  uint32_t rbase = 0, wpos = 0;
+#pragma unroll
+  for (int j = 0; j < RD; ++j) row[j] = 0;
+  // the row to memory: ONE aligned piece while it lies inside the slot (bytes behind wpos are not final yet
+  // and are written again by the row's real store), else exactly the bytes below wpos
+  auto row_store = [&]() {
+    if constexpr (ROWD > 0) {
+      uint8_t *dst = out + rbase;
+      if (rbase + 4u * ROWD <= out_cap) {
+#pragma unroll
+        for (int j = 0; j < ROWD; j += 4) {
+          const uint4 v4 = make_uint4(row[j], row[j + 1], row[j + 2], row[j + 3]);
+          __builtin_memcpy(dst + 4 * j, &v4, 16);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < ROWD; ++j) {
+          const uint32_t p = rbase + 4u * j, w = row[j];
+          if (p + 4u <= wpos) {
+            __builtin_memcpy(dst + 4 * j, &w, 4);
+          } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              if (p + t < wpos) dst[4 * j + t] = (uint8_t)(w >> (8 * t));
+          }
+        }
+      }
+    }
+  };
   out = P.out;
   out_cap = 0;
   b.in = P.in;
@@ -1134,7 +1228,17 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
         } else if (n == 0) {
           serr = E_EOF;
         } else {
-          for (uint32_t i = 0; i < n; ++i) out[opos + i] = b.in[p + i];
+          if constexpr (ROWD > 0) {
+            // through the literal registers (empty here: the end-of-block symbol flushed them), so that the
+            // raw bytes reach the row in order in this step's phase (2)
+            uint64_t raw = 0;
+            for (uint32_t i = 0; i < n; ++i) raw |= (uint64_t)b.in[p + i] << (8u * i);
+            lit_lo = (uint32_t)raw;
+            lit_hi = (uint32_t)(raw >> 32);
+            lit_n = n;
+          } else {
+            for (uint32_t i = 0; i < n; ++i) out[opos + i] = b.in[p + i];
+          }
           opos += n;
           b.hi = (p + n) * 8u;
           copy_len -= n;
@@ -1270,6 +1374,35 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
       b.w2 = crossed == 1u ? o3 : o4;
       b.widx += crossed;
     }
+    if constexpr (ROWD > 0) {
+      // this step's bytes -- the copy chunk, then the literals if they are due -- as ONE run at wpos
+      const bool flush_lits = lit_n != 0 && (lit_n >= 4u || state != S_SYM || new_match);
+      if (__ballot(k != 0 || flush_lits) != 0) {
+        uint32_t a[6];
+        {
+          uint32_t d[4] = {pend_lo, pend_hi, pend_2, pend_3};
+          row_keep_first(d, k);
+          a[0] = d[0], a[1] = d[1], a[2] = d[2], a[3] = d[3], a[4] = 0u, a[5] = 0u;
+        }
+        row_join(a, flush_lits ? lit_lo : 0u, flush_lits ? lit_hi : 0u, k);
+        uint32_t f[ROWD + 6];
+        row_place<ROWD>(f, a, wpos - rbase);
+#pragma unroll
+        for (int j = 0; j < ROWD; ++j) row[j] |= f[j];
+        wpos += k + (flush_lits ? lit_n : 0u);
+        copy_len -= k;
+        if (flush_lits) {
+          lit_n = 0;
+          lit_lo = lit_hi = 0;
+        }
+        if (wpos - rbase >= 4u * ROWD) {  // the row is full: store it, go on with what ran over
+          row_store();
+#pragma unroll
+          for (int j = 0; j < ROWD; ++j) row[j] = j < 6 ? f[ROWD + j] : 0u;
+          rbase += 4u * ROWD;
+        }
+      }
+    } else {
     // Every lane-store is its own cache line, so stores are kept few and wide.  A store may
     // write (inside the stream's slot) past the bytes that are final: the lane's next store starts
     // right after the final ones and overwrites the rest, and nothing reads them before that.
@@ -1328,6 +1461,7 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
       lit_n = 0;
       lit_lo = lit_hi = 0;
     }
+    }
     if (new_match) {
       copy_len = match_len;
       copy_dist = new_dist;
@@ -1340,16 +1474,24 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
     }
     if (state != S_STORED && copy_len != 0) {
       const uint8_t *src = out + opos - copy_dist;
+      if constexpr (ROWD > 0) {
+        // the 16 bytes about to be requested may reach into the row: memory must hold them first (the same
+        // lane's store -> load order is the hardware's, as for every copy that reads what the lane has just
+        // written)
+        if (opos - copy_dist + 16u > rbase && wpos > rbase) row_store();
+      }
       // (streaming loads: the history is not read again soon, and the lines they would displace
       // in L2 are the output lines the lanes are still filling)
       if (opos - copy_dist + 16u <= out_cap) {  // the read stays inside this stream's slot
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         typedef u32x4 u128u __attribute__((aligned(1)));
-        const u32x4 hv = __builtin_nontemporal_load(reinterpret_cast<const u128u *>(src));
-        pend_lo = hv.x;
-        pend_hi = hv.y;
-        pend_2 = hv.z;
-        pend_3 = hv.w;
+        {
+          const u32x4 hv = __builtin_nontemporal_load(reinterpret_cast<const u128u *>(src));
+          pend_lo = hv.x;
+          pend_hi = hv.y;
+          pend_2 = hv.z;
+          pend_3 = hv.w;
+        }
       } else {
         uint32_t n = copy_len < copy_dist ? copy_len : copy_dist;
         if (n > 16u) n = 16u;
@@ -1363,15 +1505,20 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
       }
     }
   }
+  if constexpr (ROWD > 0) {
+    if (have && wpos > rbase) row_store();  // what the row still holds (every path ends here: errors too)
+  }
   if (have) {
     P.out_len[sid] = opos;
     P.status[sid] = err;
     P.err_off[sid] = err == E_CORRUPT ? (long long)(in_base + sb_roffset(b)) : -1;
   }
 }
-template __global__ void inflate_simt_kernel<64>(InfParams);
-template __global__ void inflate_simt_kernel<32>(InfParams);
-template __global__ void inflate_simt_kernel<16>(InfParams);
+template __global__ void inflate_simt_kernel<64, 0>(InfParams);
+template __global__ void inflate_simt_kernel<64, 8>(InfParams);
+template __global__ void inflate_simt_kernel<64, 16>(InfParams);
+template __global__ void inflate_simt_kernel<32, 0>(InfParams);
+template __global__ void inflate_simt_kernel<16, 0>(InfParams);
 
 size_t inflate_simt_lds_bytes(int lanes_per_wave) { return (size_t)kLaneWords * lanes_per_wave * sizeof(uint16_t); }
 size_t inflate_simt_lens_bytes(uint32_t blocks) { return (size_t)blocks * 64 * kLensDwords * sizeof(uint32_t); }
