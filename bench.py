@@ -105,16 +105,20 @@ def cpu_info():
     return info
 
 
-def pmc_traffic(name, key, flate, args, group="lz77"):
+def pmc_traffic(name, key, flate, args, group="lz77", split=None):
     """HBM bytes per launch from the rocprofv3 --pmc passes kept in profiles/ (FETCH_SIZE and
     WRITE_SIZE collected in separate passes, units/corrections as MI355X_MICROARCH.md prescribes:
     see profiles/r02/README.md) -- but only when that collection describes the code being timed:
     the file carries the source hash of the library it was collected on (tools/traffic_reduce.py,
-    flate_hip_build_id) and the run must use the default launch options.  Returns
-    (bytes or None, info dict for the bench line)."""
+    flate_hip_build_id) and the run must use the default launch options.
+    split = (streams the LDS-table blocks took, streams the guests took) in THIS run: the match finder's
+    figure was collected with the queue split fixed (rocprofv3 serialises the two kernels) and the guests'
+    share moves it, so each kernel's bytes are scaled from the collection's split to this run's -- the
+    figure then describes the timed launch; the collected one and both splits are reported beside it.
+    Returns (bytes or None, info dict for the bench line)."""
     tuned = bool(args.option) or args.no_guests
     lib_id = flate.id_component(flate.build_id(), group)
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", rnd, name)
         try:
             d = json.load(open(path))[key]
@@ -127,6 +131,15 @@ def pmc_traffic(name, key, flate, args, group="lz77"):
         if tuned or got_id is None or got_id != lib_id:
             src["traffic_stale"] = True  # other sources, or non-default launch options: not quoted
             return None, src
+        qs = d.get("queue_split") or {}
+        if split and qs.get("lds_table_blocks") and qs.get("l2_table_guest_blocks") and split[0] and split[1]:
+            lds = sum(v["hbm_bytes_per_launch"] for k, v in d.get("kernels", {}).items() if "lz77_wave_kernel" in k)
+            gst = sum(v["hbm_bytes_per_launch"] for k, v in d.get("kernels", {}).items() if "lz77_guest_kernel" in k)
+            if lds and gst:
+                src.update({"as_collected": val, "collected_at_split": [qs["lds_table_blocks"], qs["l2_table_guest_blocks"]],
+                            "this_run_split": [int(split[0]), int(split[1])],
+                            "rule": "each kernel's bytes scaled by its streams in this run / in the collection"})
+                val = int(lds * split[0] / qs["lds_table_blocks"] + gst * split[1] / qs["l2_table_guest_blocks"])
         return val, src
     return None, {"file": None, "this_build": lib_id}
 
@@ -528,7 +541,8 @@ def bench_deflate(args, env, host, d_in, in_off, n, blen):
     checked = ("bit-exact vs oracle (%d streams compared)" % verified) if verified else "parity not checked in this run"
     traffic, traffic_src = None, None
     if args.kind == "text" and n == 16384 and blen == 65536:
-        traffic, traffic_src = pmc_traffic("lz77_traffic.json", "lz77_default_16384x65536_text", flate, args)
+        traffic, traffic_src = pmc_traffic("lz77_traffic.json", "lz77_default_16384x65536_text", flate, args,
+                                           split=(split["lds_table_blocks"], split["l2_table_guest_blocks"]) if split else None)
     return {
         "metric": "GiB/s uncompressed throughput (encode), 64 KiB blocks, deflate-fast",
         "value": round(value, 3), "unit": "GiB/s", "n_gpus": world, "steps": steps,

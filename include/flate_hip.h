@@ -112,6 +112,9 @@ int flate_hip_set_stream(flate_hip_ctx *ctx, void *hip_stream);
  *                        (long token lists, 16 KiB history ring), 2 = the large-batch one
  *   "inflate_lanes"      streams per wavefront of that decoder: 0 = chosen from the batch size
  *                        (default), or 16 / 32 / 64
+ *   "inflate_row_dwords" the lane-per-stream decoder's output row (64-lane form): a lane collects
+ *                        this many dwords of its output in registers and stores whole aligned
+ *                        pieces: 0 = every store goes straight to memory, 8 (default), 16
  *   "spin_limit_polls"   the persistent kernels' waits (a window that another block is still
  *                        producing) give up after this many
  *                        polls and the call returns FLATE_HIP_E_INTERNAL (default 8 Mi polls,

@@ -18,7 +18,12 @@ cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/$tag/stats -o p --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-extra > gpurun_out/$tag/bench_under_rocprof.json 2> gpurun_out/$tag/rocprof.err
 if [ -n "$FLATE_COLLECT_LITE" ]; then echo collected-lite; exit 0; fi
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/$tag/stats_inf16k -o p --output-format csv -- python3 bench.py --mode inflate --streams 16384 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/$tag/inflate16k_under_rocprof.json 2> gpurun_out/$tag/rocprof_inf16k.err
-tools/traffic_collect.sh ${tag}_c2 16384 65536 > gpurun_out/$tag/traffic_c2.json 2> gpurun_out/$tag/traffic_c2.err
+# the same for config 5 (inflate_simt_kernel) and config 3 (lz77_*_kernel<true>), the program directly behind `--`
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d gpurun_out/$tag/stats_c5 -o p --output-format csv -- python3 bench.py --mode inflate --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/$tag/config5_under_rocprof.json 2> gpurun_out/$tag/rocprof_c5.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/$tag/stats_c3 -o p --output-format csv -- python3 bench.py --streams 4096 --stream-len 262144 --steps 10 --warmup 3 --no-extra --no-cpu-baseline > gpurun_out/$tag/config3_under_rocprof.json 2> gpurun_out/$tag/rocprof_c3.err
+# fabric traffic of the match finder AT THE QUEUE SPLIT OF THE HEADLINE RUN ABOVE (the guests' share moves the figure)
+K=$(python3 -c "import json;d=json.loads(open('gpurun_out/$tag/bench.json').read().strip().splitlines()[-1]);print(d['config']['lz77_streams_by_kernel']['lds_table_blocks'])")
+FLATE_TRAFFIC_SPLIT=$K tools/traffic_collect.sh ${tag}_c2 16384 65536 > gpurun_out/$tag/traffic_c2.json 2> gpurun_out/$tag/traffic_c2.err
 tools/traffic_collect.sh ${tag}_c3 4096 262144 "--option window_units=0" > gpurun_out/$tag/traffic_c3.json 2> gpurun_out/$tag/traffic_c3.err
 tools/inflate_traffic.sh ${tag}_inf > gpurun_out/$tag/traffic_inflate.json 2> gpurun_out/$tag/traffic_inflate.err
 tools/inflate_traffic.sh ${tag}_inf16k 16384 > gpurun_out/$tag/traffic_inflate_16k.json 2> gpurun_out/$tag/traffic_inflate_16k.err

@@ -18,6 +18,12 @@ for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recurs
     shutil.copy(f, os.path.join(dst, pre + "_kernel_stats.csv"))
 for f in glob.glob(os.path.join(src, "stats_inf16k", "**", "*kernel_stats.csv"), recursive=True):
     shutil.copy(f, os.path.join(dst, pre + "_inflate16k_kernel_stats.csv"))
+for sub, out in (("stats_c5", pre + "_config5_inflate_kernel_stats.csv"), ("stats_c3", pre + "_config3_kernel_stats.csv")):
+    for f in glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True):
+        shutil.copy(f, os.path.join(dst, out))
+for name, out in (("config5_under_rocprof.json", pre + "_config5_under_rocprof.json"), ("config3_under_rocprof.json", pre + "_config3_under_rocprof.json")):
+    if os.path.exists(os.path.join(src, name)) and os.path.getsize(os.path.join(src, name)) > 10:
+        json.dump(last_json(os.path.join(src, name)), open(os.path.join(dst, out), "w"), indent=1)
 if os.path.exists(os.path.join(src, "inflate16k_under_rocprof.json")):
     json.dump(last_json(os.path.join(src, "inflate16k_under_rocprof.json")),
               open(os.path.join(dst, pre + "_inflate16k_under_rocprof.json"), "w"), indent=1)
