@@ -9,15 +9,21 @@ from util import flate, make_streams
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["wave_per_stream", "lane_per_stream", "speculative_wave_small_batch",
-                                        "speculative_wave_large_batch"])
+@pytest.fixture(scope="module", params=["wave_per_stream", "lane_per_stream", "lane_per_stream_64_row8",
+                                        "lane_per_stream_64_row16", "lane_per_stream_64_norow",
+                                        "speculative_wave_small_batch", "speculative_wave_large_batch"])
 def eng(request):
-    """All three inflater kernels (both builds of the third) must pass every test: the options force one of them."""
+    """All three inflater kernels (both builds of the third; the lane-per-stream one by batch size -- small test
+    batches take its 16-lane form -- and in its 64-lane form with an output row of 8 and 16 dwords and without
+    one) must pass every test: the options force one of them."""
     flate.build()
     e = flate.FlateEngine(0)
-    e.set_option("inflate_simt_min_streams", 0 if request.param == "lane_per_stream" else 1 << 30)
+    e.set_option("inflate_simt_min_streams", 0 if request.param.startswith("lane_per_stream") else 1 << 30)
     e.set_option("inflate_spec", 2 if request.param.startswith("speculative_wave") else 0)
     e.set_option("inflate_spec_shape", 1 if request.param.endswith("small_batch") else 2)
+    if request.param.startswith("lane_per_stream_64"):
+        e.set_option("inflate_lanes", 64)
+        e.set_option("inflate_row_dwords", {"row8": 8, "row16": 16, "norow": 0}[request.param.rsplit("_", 1)[1]])
     yield e
     e.close()
 
