@@ -1485,13 +1485,15 @@ __global__ __launch_bounds__(64) void inflate_simt_kernel(InfParams P) {
       if (opos - copy_dist + 16u <= out_cap) {  // the read stays inside this stream's slot
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         typedef u32x4 u128u __attribute__((aligned(1)));
-        {
-          const u32x4 hv = __builtin_nontemporal_load(reinterpret_cast<const u128u *>(src));
-          pend_lo = hv.x;
-          pend_hi = hv.y;
-          pend_2 = hv.z;
-          pend_3 = hv.w;
-        }
+#ifdef FLATE_EXP_NO_HISTORY_LOAD  // TIMING EXPERIMENT ONLY (wrong bytes on purpose): what the kernel costs without its history fetches
+        pend_lo = pend_hi = pend_2 = pend_3 = (uint32_t)(uintptr_t)src;
+#else
+        const u32x4 hv = __builtin_nontemporal_load(reinterpret_cast<const u128u *>(src));
+        pend_lo = hv.x;
+        pend_hi = hv.y;
+        pend_2 = hv.z;
+        pend_3 = hv.w;
+#endif
       } else {
         uint32_t n = copy_len < copy_dist ? copy_len : copy_dist;
         if (n > 16u) n = 16u;
