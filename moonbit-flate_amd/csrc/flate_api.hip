@@ -403,7 +403,7 @@ int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, cons
     // profiling split, [4..5] what the LDS-table launches took, [6..7] window-unit head / tail
     HIP_TRY(c, hipMemsetAsync(c->d_queue.p, 0, 32, c->stream));
   }
-#ifdef FLATE_LZ_STAMPS
+#if defined(FLATE_LZ_STAMPS) || defined(FLATE_LZ_FINISH)
   if ((rc = ensure(c, c->d_debug, (size_t)pl.n_chunks * 64 + 64))) return rc;
   HIP_TRY(c, hipMemsetAsync(c->d_debug.p, 0, (size_t)pl.n_chunks * 64, c->stream));
   P.debug = (uint64_t *)c->d_debug.p;
@@ -1646,8 +1646,8 @@ int flate_hip_lz77_matches(flate_hip_ctx *c, const uint8_t *in, const uint64_t *
   return collect_timing(c, used);
 }
 
-#if defined(FLATE_LZ_STAMPS)
-// diagnostic builds only: per-chunk phase cycle sums of the last match-finder launch
+#if defined(FLATE_LZ_STAMPS) || defined(FLATE_LZ_FINISH)
+// diagnostic builds only: per-chunk phase cycle sums (or start / finish times) of the last match-finder launch
 int flate_hip_debug_lz_stamps(flate_hip_ctx *c, uint64_t *out, uint32_t max_chunks) {
   uint32_t k = c->debug_chunks < max_chunks ? c->debug_chunks : max_chunks;
   if (hipMemcpy(out, c->d_debug.p, (size_t)k * 64, hipMemcpyDeviceToHost) != hipSuccess) return -3;

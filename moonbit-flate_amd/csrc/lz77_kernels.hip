@@ -239,6 +239,9 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
   const ChunkGeom g = stream_geom(P, sid);
   const uint16_t *scan_tab = P.scan_off;
   uint32_t pf_val = 0, pf_sink = 0;
+#ifdef FLATE_LZ_FINISH  // diagnostic build: when did this stream start and end, on which block (100 MHz clock)
+  const uint64_t fin_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   // (w0 != 0 only in resumed launches: the stream's chunks of THIS launch are windows w0, w0+1, ...)
   const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.win0);
@@ -717,6 +720,14 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
     }
   }
   if (sweep_io) *sweep_io = next_sweep;
+#ifdef FLATE_LZ_FINISH
+  if (lane == 0 && P.debug && c_begin == 0) {
+    uint64_t *d = P.debug + (uint64_t)g.chunk0 * 8;
+    d[0] = fin_t0;
+    d[1] = __builtin_amdgcn_s_memrealtime();
+    d[2] = ((uint64_t)(GUEST ? 1u : 0u) << 32) | blockIdx.x;
+  }
+#endif
 }
 
 // Every lane of the wavefront must still be in the persistent loop.  hipcc once peeled lane 0 off
