@@ -186,9 +186,22 @@ FLATE_D uint64_t same_slot_lanes(uint32_t h, uint64_t among) {
   return ((uint64_t)hi << 32) | lo;
 }
 
+// Only the first kTagSlots slots carry a tag (the others always take the gathers).  LDS is handed out in granules of
+// 1280 bytes on gfx950 (160 KiB / 128): an LDS-table block takes 26 of them, and a guest with tags for all 16384
+// slots (4096 B) takes FOUR -- 4 x 26 + 6 x 4 = 128: six guests per CU are resident beside four tables, whatever
+// the launch asks for (profiles/r05/README.md section 5).  15360 tagged slots are 3840 B = THREE granules: eight.
+#ifndef FLATE_LZ_TAG_SLOTS
+#define FLATE_LZ_TAG_SLOTS 16384
+#endif
+constexpr uint32_t kTagSlots = FLATE_LZ_TAG_SLOTS;
+static_assert(kTagSlots % 1024 == 0 && kTagSlots <= (uint32_t)kTableSize, "whole rounds of 64 lanes x 16 slots");
 FLATE_D uint32_t tag_of(uint32_t cv) { return ((cv * 0x1e35a7bdu) >> 16) & 3u; }
-FLATE_D uint32_t tag_get(const uint32_t *tags, uint32_t h) { return (tags[h >> 4] >> (2u * (h & 15u))) & 3u; }
+FLATE_D bool tag_says_no(const uint32_t *tags, uint32_t h, uint32_t cv) {
+  if (kTagSlots < (uint32_t)kTableSize && h >= kTagSlots) return false;
+  return ((tags[h >> 4] >> (2u * (h & 15u))) & 3u) != tag_of(cv);
+}
 FLATE_D void tag_set(uint32_t *tags, uint32_t h, uint32_t t) {
+  if (kTagSlots < (uint32_t)kTableSize && h >= kTagSlots) return;
   const uint32_t sh = 2u * (h & 15u);
   atomicAnd(&tags[h >> 4], ~(3u << sh));
   atomicOr(&tags[h >> 4], t << sh);
@@ -200,7 +213,7 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
                          uint32_t *sweep_io = nullptr, uint32_t *tags = nullptr) {
   using E = uint16_t;
   if (tags && c_begin == 0)
-    for (int i = lane; i < kTableSize / 16; i += 64) tags[i] = 0;
+    for (int i = lane; i < (int)kTagSlots / 16; i += 64) tags[i] = 0;
   if (c_begin == 0) {
     uint4 *t4 = reinterpret_cast<uint4 *>(table);
     const uint32_t fill = MULTI ? (((0u - kMarkerBack + 1u) & 0xffffu) * 0x10001u) : 0u;
@@ -295,7 +308,7 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
         if (e1) {
           own = pre_valid ? own_pre : ld128(src + q);
           h = hash4(own.x);
-          maybe = !tags || tag_get(tags, h) == tag_of(own.x);
+          maybe = !tags || !tag_says_no(tags, h, own.x);
           if (maybe) old = table[h];
         }
         pre_valid = false;
@@ -839,7 +852,7 @@ FLATE_D uint32_t uq_run(const LzParams &P, const UqUnit u, uint16_t *table, int 
     const uint8_t *stream = P.in + P.in_off[sid];
     const uint32_t W = u.c * (uint32_t)kMaxStoreBlockSize;
     if (tags) {
-      for (int i = lane; i < kTableSize / 16; i += 64) tags[i] = 0;
+      for (int i = lane; i < (int)kTagSlots / 16; i += 64) tags[i] = 0;
       __syncthreads();
     }
     // (sixteen loads in flight per lane: one at a time, each waited for before its store, was 128
@@ -867,7 +880,7 @@ FLATE_D uint32_t uq_run(const LzParams &P, const UqUnit u, uint16_t *table, int 
             const uint32_t slot = (w[half * 8 + j / 2] >> (16 * (j & 1))) & 0xffffu;
             const uint32_t back = (W + 1u - slot) & 0xffffu;
             const uint32_t h = 2u * (uint32_t)(i0 + 64 * (half * 8 + j / 2)) + (uint32_t)(j & 1);
-            if (back != 0u && back <= W) atomicOr(&tags[h >> 4], tag_of(cv[j]) << (2u * (h & 15u)));
+            if (back != 0u && back <= W && h < kTagSlots) atomicOr(&tags[h >> 4], tag_of(cv[j]) << (2u * (h & 15u)));
           }
         }
       }
@@ -947,7 +960,7 @@ __global__ __launch_bounds__(64) void lz77_guest_kernel(LzParams P) {
   // (round 2 gave multi-window guests no tags: -7 % with them at equal geometry, but the window
   // units hand a stream from block to block and the tags did not travel; round 3 rebuilds them at the
   // start of a unit instead, see uq_run)
-  __shared__ uint32_t tag_mem[kTableSize / 16];  // 4 KiB: see tag_of
+  __shared__ uint32_t tag_mem[kTagSlots / 16];  // see tag_of, kTagSlots
   uint32_t *tags = tag_mem;
   if (MULTI && P.uq_ready) {  // persistent, one window at a time, table in place (see uq_run)
     uint32_t push_word = 0;
