@@ -325,10 +325,38 @@ def main():
             res["extra"] = extra_legs(args, env)
     if rank == 0:
         print(json.dumps(res))
+        sys.stdout.flush()
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        # (the line is out: nothing behind it may keep the process alive -- a rank that left a stuck side measurement
+        # behind, or whose peers did, ends hard instead of waiting in a barrier)
+        done = False
+        if not env.get("hard_exit"):
+            done, _ = run_with_time_limit(lambda: (dist.barrier(), dist.destroy_process_group()), env, 120.0)
+        if not done:
+            sys.stderr.flush()
+            os._exit(0)
     eng.close()
+
+
+def run_with_time_limit(fn, env, seconds):
+    """fn() in a helper thread (the calling thread only waits): (True, its result or the exception it raised), or
+    (False, None) when it is still running after `seconds` -- a collective that never completes cannot be cancelled,
+    only left behind."""
+    import threading
+    box = {}
+
+    def work():
+        try:
+            if env["cuda"]:
+                env["torch"].cuda.set_device(env["dev"])
+            box["val"] = fn()
+        except BaseException as e:  # noqa: BLE001  (SystemExit included: the caller re-raises it)
+            box["val"] = e
+
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    t.join(seconds)
+    return (not t.is_alive()), box.get("val")
 
 
 def sync_all(env):
@@ -482,8 +510,24 @@ def bench_deflate(args, env, host, d_in, in_off, n, blen):
         native_ok = (env["cuda"] and dist.get_backend() == "nccl") or hasattr(eng, "native_comm")
         if not args.no_native_gather and native_ok:
             # the same exchange through include/flate_hip.h (what a MoonBit / C++ host calls): ON by default, so
-            # that the first run on a multi-GPU node exercises flate_hip_gather_* over real RCCL / xGMI
-            try:
+            # that the first run on a multi-GPU node exercises flate_hip_gather_* over real RCCL / xGMI.
+            # It is a side measurement that has never run on more than one real GPU: it may fail, it must never
+            # cost the run its line, and it must never HANG it -- (1) every rank first probes, without a
+            # collective, that it can bind RCCL, and the ranks agree on that before anyone enters the collective
+            # communicator set-up; (2) the whole section runs under a time limit in a helper thread; a rank whose
+            # section is still stuck in a collective when the limit passes records that and leaves the process
+            # with os._exit once its line is out (main()).
+            def native_section():
+                ok_local, why = 1, ""
+                if not hasattr(eng, "native_comm"):
+                    try:
+                        shard.NativeComm.probe(eng)
+                    except Exception as e:  # noqa: BLE001
+                        ok_local, why = 0, "%s: %s" % (type(e).__name__, e)
+                flag = torch.tensor([ok_local], dtype=torch.int32, device=env["dev"] if dist.get_backend() == "nccl" else "cpu")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 0:
+                    raise RuntimeError("a rank cannot bind RCCL for the C-ABI exchange (this rank: %s)" % (why or "ok"))
                 comm = eng.native_comm(rank, world, dist) if hasattr(eng, "native_comm") else shard.NativeComm(eng, rank, world, dist)
                 nat = {}
                 for mode in ("allgather", "sendrecv"):
@@ -504,10 +548,20 @@ def bench_deflate(args, env, host, d_in, in_off, n, blen):
                     nat[mode + "_frac_of_xgmi"] = round(gbs / XGMI_PEAK_GBS, 4)
                 nat["compared_streams"] = len(range(0, world * n, max(1, world * n // 64)))
                 comm.close()
-                gather_info["c_abi"] = nat
-            except Exception as e:  # noqa: BLE001  (a missing RCCL must not cost the run its line; a mismatch does, above)
-                gather_info["c_abi_error"] = "%s: %s" % (type(e).__name__, e)
+                return nat
+
+            done, val = run_with_time_limit(native_section, env, float(os.environ.get("FLATE_BENCH_NATIVE_LIMIT_S", "240")))
+            if not done:
+                env["hard_exit"] = True
+                gather_info["c_abi_error"] = "the C-ABI exchange did not finish within its time limit; left behind, the process ends with os._exit"
+                print("bench: " + gather_info["c_abi_error"], file=sys.stderr)
+            elif isinstance(val, SystemExit):
+                raise val  # a mismatch ends the run
+            elif isinstance(val, BaseException):  # (a missing RCCL must not cost the run its line)
+                gather_info["c_abi_error"] = "%s: %s" % (type(val).__name__, val)
                 print("bench: C-ABI exchange failed: %s" % gather_info["c_abi_error"], file=sys.stderr)
+            else:
+                gather_info["c_abi"] = val
         mins = [gather_info[m + "_ms"]["min"] for m in ("allgather", "sendrecv") if m + "_ms" in gather_info]
         if mins:
             best = min(mins)

@@ -222,6 +222,16 @@ class NativeComm:
         eng._check(self._L.flate_hip_comm_init(eng._ctx, uid.ctypes.data, self.rank, self.world,
                                                C.byref(self._comm)))
 
+    @staticmethod
+    def probe(eng):
+        """Can this process bind RCCL for the C-ABI exchange?  No collective: flate_hip_comm_unique_id binds the
+        library at its first use and fails with a message if it cannot (raises FlateError then).  Callers that
+        are about to create communicators on several ranks agree on this first, so that no rank is left alone
+        in the collective set-up."""
+        from . import _lib
+        uid = np.zeros(128, dtype=np.uint8)
+        eng._check(_lib.load().flate_hip_comm_unique_id(uid.ctypes.data))
+
     def close(self):
         if self._comm:
             self._L.flate_hip_comm_destroy(self._comm)

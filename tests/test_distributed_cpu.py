@@ -148,3 +148,29 @@ def test_bench_rejects_a_world_size_that_contradicts_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env,
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def test_bench_line_survives_a_c_abi_exchange_that_hangs():
+    """The default N > 1 run must never lose its line to the side measurement: with one rank stuck outside the
+    collective (the other then waits inside it for ever) every rank gives up at the time limit, rank 0's line is
+    out -- with the failure recorded -- and every process ends."""
+    import json
+    import subprocess
+    import time
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["FLATE_BENCH_TEST_ENGINE"] = "tests.cpu_engine:OracleEngine"
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    env["FLATE_TEST_STUCK_RANK"] = "1"
+    env["FLATE_BENCH_NATIVE_LIMIT_S"] = "5"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--streams", "64", "--stream-len", "4096"],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert time.time() - t0 < 200
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    g = line["config"]["gather"]
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    assert "c_abi" not in g and "time limit" in g["c_abi_error"]
