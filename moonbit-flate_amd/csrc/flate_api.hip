@@ -466,16 +466,19 @@ int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, cons
         (void)hipEventRecord(c->ev_fork, c->stream);
         (void)hipStreamWaitEvent(c->guest_stream, c->ev_fork, 0);
         uint32_t resident = c->resident_blocks < count ? c->resident_blocks : count;
+        // The LDS-table kernel is submitted FIRST: its blocks need 26 contiguous LDS granules each, and guests that
+        // reach a CU before them can leave it with room for three (measured: -1.4 % with this order, section 7 of
+        // profiles/r05/README.md).
         if (multi) {
+          hipLaunchKernelGGL(lz77_wave_kernel<true>, dim3(resident), dim3(64), 0, c->stream, R);
           hipLaunchKernelGGL(lz77_guest_kernel<true>, dim3((uint32_t)c->guest_blocks), dim3(64), 0,
                              c->guest_stream, G);
           (void)hipEventRecord(c->ev_join, c->guest_stream);
-          hipLaunchKernelGGL(lz77_wave_kernel<true>, dim3(resident), dim3(64), 0, c->stream, R);
         } else {
+          hipLaunchKernelGGL(lz77_wave_kernel<false>, dim3(resident), dim3(64), 0, c->stream, R);
           hipLaunchKernelGGL(lz77_guest_kernel<false>, dim3((uint32_t)c->guest_blocks), dim3(64), 0,
                              c->guest_stream, G);
           (void)hipEventRecord(c->ev_join, c->guest_stream);
-          hipLaunchKernelGGL(lz77_wave_kernel<false>, dim3(resident), dim3(64), 0, c->stream, R);
         }
         (void)hipStreamWaitEvent(c->stream, c->ev_join, 0);
       };
@@ -576,8 +579,12 @@ int flate_hip_init(int device, flate_hip_ctx **out) {
     c->num_cus = (uint32_t)cus;
     c->guest_min = 5u * (uint32_t)cus;  // measured: 1024 streams 1.72 ms as one block per stream vs 2.15 ms
                                         // persistent; 1280: 3.41 vs 2.35; 2048: 3.61 vs 2.76; 3072: 5.55 vs 3.96
+    // LDS comes in 128 granules of 1280 B per CU: an LDS-table block (32768 B) takes 26, a guest (4096 B of slot
+    // tags) 4, so 4 + 6 blocks fill a CU exactly.  Launching MORE guests than fit (rounds 2-4 asked for 6.5 per CU)
+    // lets guests that arrive first take the granules of an LDS-table block: most processes then ran 3.5 + 6.5
+    // blocks per CU and the match finder 4 % slower (profiles/r05/README.md section 7).  Ask for what fits.
     c->resident_blocks = 4u * (uint32_t)cus;
-    c->guest_blocks = 13 * cus / 2;
+    c->guest_blocks = 6 * cus;
   }
   if (const char *e = getenv("FLATE_HIP_GUEST_BLOCKS")) c->guest_blocks = atoi(e) < 0 ? 0 : atoi(e);
   if (const char *e = getenv("FLATE_HIP_GUEST_MIN")) c->guest_min = (uint32_t)atoi(e);
