@@ -395,8 +395,13 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
           const bool slow = !(fv < fd) || tf >= 16;
           const bool ends = B + fv + tf >= s_limit;
           const int nxt = fv + tf - 1;
+#ifdef FLATE_LZ_TERM_SHORTCUT  // (A/B builds) bit 19: no candidate and no same-slot lane among my probe lanes of this batch
+          const bool off_batch = INTERIOR && fv == 64 && fd == 64;
+#else
+          constexpr bool off_batch = false;
+#endif
           ev = (uint32_t)(fv & 127) | ((uint32_t)tf << 8) | (slow ? 1u << 16 : 0u) |
-               (ends ? 1u << 17 : 0u) | ((ends || nxt > kDenseKeep) ? 1u << 18 : 0u) |
+               (ends ? 1u << 17 : 0u) | ((ends || nxt > kDenseKeep) ? 1u << 18 : 0u) | (off_batch ? 1u << 19 : 0u) |
                ((uint32_t)(nxt & 255) << 24);
         }
         STAMP(t2);
@@ -463,6 +468,11 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
             if (x & (1u << 17)) done = true;
             break;
           }
+#ifdef FLATE_LZ_TERM_SHORTCUT
+          // the batch's usual last event (it starts at a lane a > 0 and finds nothing before lane 64): the general
+          // path would walk its probe lanes, find no match and leave without changing INS or M
+          if (INTERIOR && (x & (1u << 19)) && a != 0) break;
+#endif
           // ---- general event (shared slots, long matches, end of scan) ----
           STAMP(tg0);
           const uint64_t FINS = fast_inserts(VISall);
