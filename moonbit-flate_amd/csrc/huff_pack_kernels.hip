@@ -57,7 +57,15 @@ struct Shared {
   uint32_t key[288];    // sort keys (freq << 9 | symbol) of the symbols in use
   uint32_t sfreq[288];  // leaves ascending by (freq, symbol)
   alignas(8) uint32_t lv[2][576];  // package-merge level lists (ping-pong)
-  uint32_t pairs[288];
+#ifdef FLATE_HUFF_PAIRS_OWN  // (A/B builds: the layout of rounds 3-4, 12088 B = 10 LDS granules of 1280 B = 12 wavefronts per CU)
+  uint32_t pairs_mem[288];
+  FLATE_D uint32_t *pairs() { return pairs_mem; }
+#else
+  // the pair sums of a level live in the sort keys, which are dead once the leaves are sorted (a level of the
+  // 19-symbol codegen code has at most 9 pairs: 36 bytes, in front of the codegen items at key + 128): 10936 B =
+  // 9 granules = 14 wavefronts per CU
+  FLATE_D uint32_t *pairs() { return key; }
+#endif
   uint32_t leaf_bits[kPmLevels][18];  // per level: bit r set <=> item r of the merged list is a leaf
   uint8_t slen[288];
   uint32_t cg_n;           // number of codegen items
@@ -285,7 +293,7 @@ FLATE_D void build_code_sorted(Shared &sh, int n, int nsym, int max_bits, uint32
       const int j = lane + 64 * t;
       const uint2 two = j < np ? *reinterpret_cast<const uint2 *>(prev + 2 * j) : make_uint2(0u, 0u);
       ps[t] = two.x + two.y;
-      if (j < np) sh.pairs[j] = ps[t];
+      if (j < np) sh.pairs()[j] = ps[t];
     }
     __syncthreads();
     // leaf i goes to i + #pairs with sum <= leaf (a pair wins a tie, :187);
@@ -299,7 +307,7 @@ FLATE_D void build_code_sorted(Shared &sh, int n, int nsym, int max_bits, uint32
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int a = cl_[t] + s, c = cp[t] + s;
-        pv[t] = sh.pairs[(a <= np ? a : np) - 1];
+        pv[t] = sh.pairs()[(a <= np ? a : np) - 1];
         lv_[t] = sh.sfreq[(c <= n ? c : n) - 1];
       }
 #pragma unroll
@@ -1073,6 +1081,12 @@ FLATE_D void pack_block(const HuffParams &P, SharedPack &sh, BitSink &S, const B
 // write_dynamic_header (:421-471), write_tokens (:596-731), write_block_huff's byte loop
 // (:788-823), stored blocks: the stream's bits go to out + out_off[sid].
 // ---------------------------------------------------------------------------------------
+// (amdgpu_num_sgpr: a SIMD's 800 scalar registers admit floor(800 / (ceil(sgpr / 16) * 16 + 16)) wavefronts -- 6 at
+// the 105 the compiler would take, 8 at 80; the kernel is VALU-bound and wants all eight: 1.09 -> 0.93 ms)
+#ifndef FLATE_HUFF_PACK_SGPR
+#define FLATE_HUFF_PACK_SGPR 80
+#endif
+__attribute__((amdgpu_num_sgpr(FLATE_HUFF_PACK_SGPR)))
 __global__ __launch_bounds__(64) void huff_pack_kernel(HuffParams P) {
   __shared__ SharedPack sh;
   const int lane = threadIdx.x;
@@ -1179,6 +1193,7 @@ __global__ __launch_bounds__(256) void huff_zero_edges_kernel(HuffParams P, uint
     if (k >= own_lo && k < own_hi) bytes[k] = 0;
 }
 
+__attribute__((amdgpu_num_sgpr(FLATE_HUFF_PACK_SGPR)))
 __global__ __launch_bounds__(64) void huff_pack_block_kernel(HuffParams P) {
   __shared__ SharedPack sh;
   const int lane = threadIdx.x;
