@@ -55,7 +55,6 @@ struct Shared {
   uint32_t cg_cl[20];
   // code construction scratch
   uint32_t key[288];    // sort keys (freq << 9 | symbol) of the symbols in use
-  uint32_t sfreq[288];  // leaves ascending by (freq, symbol)
   alignas(8) uint32_t lv[2][576];  // package-merge level lists (ping-pong)
 #ifdef FLATE_HUFF_PAIRS_OWN  // (A/B builds: the layout of rounds 3-4, 12088 B = 10 LDS granules of 1280 B = 12 wavefronts per CU)
   uint32_t pairs_mem[288];
@@ -252,6 +251,10 @@ FLATE_D void sink_finish(BitSink &S, int lane) {
 // a lane owns items lane, lane + 64, ... (NT >= ceil(n / 64) of them).
 template <int NT>
 FLATE_D void build_code_sorted(Shared &sh, int n, int nsym, int max_bits, uint32_t *cl, int lane) {
+  // The leaves in ascending order live in the OUTPUT array until the codes are written: cl[] is not read before
+  // the last loop below, which writes every entry (10936 -> 9784 B of LDS = eight granules of 1280 B = 16
+  // wavefronts per CU, what the kernel's 120 VGPRs allow: 16384 streams are four full rounds instead of 4.6).
+  uint32_t *sfreq = cl;
   // rank sort (keys are distinct): item j of the unsorted list is leaf rank[j] of the sorted one
   uint32_t mine[NT];
   int rank[NT];
@@ -269,7 +272,7 @@ FLATE_D void build_code_sorted(Shared &sh, int n, int nsym, int max_bits, uint32
 #pragma unroll
   for (int t = 0; t < NT; ++t)
     if (lane + 64 * t < n) {
-      sh.sfreq[rank[t]] = mine[t] >> 9;   // leaves ascending by (freq, symbol), by_frequency :346
+      sfreq[rank[t]] = mine[t] >> 9;      // leaves ascending by (freq, symbol), by_frequency :346
       sh.lv[0][rank[t]] = mine[t] >> 9;   // level 1: the leaves themselves
     }
   for (int i = lane; i < kPmLevels * 18; i += 64) (&sh.leaf_bits[0][0])[i] = 0;
@@ -278,7 +281,7 @@ FLATE_D void build_code_sorted(Shared &sh, int n, int nsym, int max_bits, uint32
   const int mb = max_bits < n - 1 ? max_bits : n - 1;  // :126-129
   uint32_t lf[NT];  // my leaves of the SORTED list: i = lane + 64 t
 #pragma unroll
-  for (int t = 0; t < NT; ++t) lf[t] = lane + 64 * t < n ? sh.sfreq[lane + 64 * t] : 0u;
+  for (int t = 0; t < NT; ++t) lf[t] = lane + 64 * t < n ? sfreq[lane + 64 * t] : 0u;
   const int s0 = 1 << (31 - __builtin_clz(n));  // first step of a search over <= n elements
 
   int lp = n;  // length of the previous level's list
@@ -308,7 +311,7 @@ FLATE_D void build_code_sorted(Shared &sh, int n, int nsym, int max_bits, uint32
       for (int t = 0; t < NT; ++t) {
         const int a = cl_[t] + s, c = cp[t] + s;
         pv[t] = sh.pairs()[(a <= np ? a : np) - 1];
-        lv_[t] = sh.sfreq[(c <= n ? c : n) - 1];
+        lv_[t] = sfreq[(c <= n ? c : n) - 1];
       }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -401,7 +404,7 @@ FLATE_D void build_code_sorted(Shared &sh, int n, int nsym, int max_bits, uint32
       if (L == (uint32_t)b) code = first_code[b] + running[b] + __popcll(m & ((1ull << lane) - 1));
       running[b] += __popcll(m);
     }
-    if (L) cl[i] = (L << 16) | (__brev(code) >> (32 - L));
+    if (i < nsym) cl[i] = L ? ((L << 16) | (__brev(code) >> (32 - L))) : 0u;  // (every entry: cl held the sorted leaves)
   }
   __syncthreads();
 }
