@@ -570,8 +570,8 @@ int flate_hip_init(int device, flate_hip_ctx **out) {
     flate_hip_destroy(c);
     return FLATE_HIP_E_HIP;
   }
-  {  // 4 resident (LDS-table) + 6.5 guest (L2-table, 4 KiB of LDS slot tags each) match-finder
-     // waves per CU: measured best for single- and multi-window streams (profiles/r02/README.md)
+  {  // 4 resident (LDS-table) + 6 guest (L2-table, 4 KiB of LDS slot tags each) match-finder waves per CU:
+     // what a CU's LDS granules hold, and the measured optimum (profiles/r05/README.md sections 6-7)
     hipDeviceProp_t prop;
     int cus = 256;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
