@@ -507,7 +507,10 @@ def bench_deflate(args, env, host, d_in, in_off, n, blen):
                 gather_info[mode + "_error"] = "%s: %s" % (type(e).__name__, e)
                 break
         del side_buf
-        native_ok = (env["cuda"] and dist.get_backend() == "nccl") or hasattr(eng, "native_comm")
+        # (FLATE_BENCH_FORCE_NATIVE=1: rehearsals on a one-GPU box -- gloo between the ranks, the library's TEST build
+        # with the tests' rehearsal transport in place of RCCL -- take the same path)
+        native_ok = (env["cuda"] and (dist.get_backend() == "nccl" or os.environ.get("FLATE_BENCH_FORCE_NATIVE") == "1")) \
+            or hasattr(eng, "native_comm")
         if not args.no_native_gather and native_ok:
             # the same exchange through include/flate_hip.h (what a MoonBit / C++ host calls): ON by default, so
             # that the first run on a multi-GPU node exercises flate_hip_gather_* over real RCCL / xGMI.

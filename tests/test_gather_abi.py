@@ -185,6 +185,29 @@ def test_two_ranks_through_the_c_abi_exchange_on_one_card():
 
 
 @pytest.mark.gpu
+def test_bench_with_two_ranks_takes_the_c_abi_exchange_by_default_on_one_card():
+    """`bench.py --gpus 2` as the driver will run it on a multi-GPU node -- the exchange through the C ABI after the
+    timed region, in its guarded helper thread -- rehearsed with two ranks on ONE card: gloo between the ranks,
+    the library's test build with the rehearsal transport in place of RCCL (FLATE_BENCH_FORCE_NATIVE)."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    test_lib = importlib.import_module("moonbit-flate_amd.build").build_test()
+    env = dict(os.environ, FLATE_BENCH_BACKEND="gloo", FLATE_BENCH_FORCE_NATIVE="1", FLATE_HIP_LIB=test_lib,
+               FLATE_HIP_TEST_TRANSPORT=_rehearsal_transport(), FLATE_REHEARSAL_TIMEOUT_S="90",
+               FLATE_REHEARSAL_SLOT_MB="64")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--streams", "1536", "--cpu-sample-streams", "128"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    g = line["config"]["gather"]
+    assert line["n_gpus"] == 2 and "c_abi_error" not in g, g
+    assert g["c_abi"]["compared_streams"] >= 48 and g["c_abi"]["allgather_ms"]["mean"] > 0 and g["c_abi"]["sendrecv_ms"]["mean"] > 0
+
+
+@pytest.mark.gpu
 def test_two_ranks_over_rccl_when_the_box_has_two_gpus():
     """The same script over RCCL itself, one GPU per rank (skipped on the one-GPU boxes of this pool)."""
     import torch
