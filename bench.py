@@ -43,6 +43,9 @@ XGMI_PEAK_GBS = 7 * 153.0  # 7 links x ~153 GB/s per GPU (task statement)
 # ----------------------------------------------------------------------------------------------
 # launch
 # ----------------------------------------------------------------------------------------------
+kExitAbandoned = 3  # a rank left a stuck collective behind (its line is out and says so)
+
+
 def spawn_ranks(n):
     """Start n worker processes (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set), one GPU each.  The
     parent never initialises the GPU and never execs: it waits and returns the worst exit code."""
@@ -102,6 +105,12 @@ def cpu_info():
             break
         except (OSError, ValueError, IndexError):
             continue
+    # the threads the CPU legs run on: what the process is actually granted, never the host's nproc (256 threads under
+    # a 16-CPU cgroup measured oversubscription: 1.24 GiB/s against 1.91 on 16)
+    usable = min(info["nproc"], info.get("affinity_cpus", info["nproc"]))
+    if "cgroup_cpu_limit" in info:
+        usable = min(usable, max(1, int(info["cgroup_cpu_limit"])))
+    info["usable_cpus"] = max(1, usable)
     return info
 
 
@@ -118,7 +127,7 @@ def pmc_traffic(name, key, flate, args, group="lz77", split=None):
     Returns (bytes or None, info dict for the bench line)."""
     tuned = bool(args.option) or args.no_guests
     lib_id = flate.id_component(flate.build_id(), group)
-    for rnd in ("r05", "r04", "r03", "r02"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", rnd, name)
         try:
             d = json.load(open(path))[key]
@@ -127,7 +136,9 @@ def pmc_traffic(name, key, flate, args, group="lz77", split=None):
             continue
         got_id = flate.id_component(d.get("build_id"), group)
         src = {"file": "profiles/%s/%s" % (rnd, name), "kernels": group, "collected_on_build": got_id,
-               "git_head": d.get("git_head"), "this_build": lib_id}
+               "collected_at_git_head": d.get("git_head"), "this_build": lib_id,
+               "note": "the figure is quoted only when collected_on_build == this_build (hashes of the kernels' sources); "
+                       "commits after collected_at_git_head did not touch them"}
         if tuned or got_id is None or got_id != lib_id:
             src["traffic_stale"] = True  # other sources, or non-default launch options: not quoted
             return None, src
@@ -161,7 +172,7 @@ def cpu_leg(host, in_off, n, blen, sample_streams, g_out=None, g_off=None):
     from oracle import pyoracle
     ns = min(sample_streams, n)
     info = cpu_info()
-    cores = min(info["nproc"], 16)
+    cores = info["usable_cpus"]
     t1 = time.perf_counter()
     o_buf, o_off, o_len = pyoracle.deflate_batch(host[:ns * blen], in_off[:ns + 1], nthreads=cores)
     cdt = time.perf_counter() - t1
@@ -169,15 +180,6 @@ def cpu_leg(host, in_off, n, blen, sample_streams, g_out=None, g_off=None):
     t1 = time.perf_counter()
     pyoracle.deflate_batch(host[:n1 * blen], in_off[:n1 + 1], nthreads=1)
     cdt1 = time.perf_counter() - t1
-    # the box's own cores -- `nproc` threads over the same sample (best of two passes:
-    # the first one pays for the threads' first touch of their output slots)
-    nall = info["nproc"]
-    cdta = None
-    for _ in range(2):
-        t1 = time.perf_counter()
-        pyoracle.deflate_batch(host[:ns * blen], in_off[:ns + 1], nthreads=nall)
-        d = time.perf_counter() - t1
-        cdta = d if cdta is None else min(cdta, d)
     # SURVEY 8(d) context line: libz deflate level 1, raw, the same threads and sample.  A DIFFERENT
     # algorithm (zlib's deflate_fast with a hash chain, not the reference's) -- context, not parity.
     import zlib
@@ -205,8 +207,6 @@ def cpu_leg(host, in_off, n, blen, sample_streams, g_out=None, g_off=None):
                   % (ns, n, ns * blen >> 20, cores, cdt),
         "single_thread": {"value": round(n1 * blen / cdt1 / 2**30, 4), "unit": "GiB/s",
                           "sample": "first %d streams (%d MiB), %.1f s wall" % (n1, n1 * blen >> 20, cdt1)},
-        "all_cores": {"value": round(ns * blen / cdta / 2**30, 4), "unit": "GiB/s", "threads": nall,
-                      "sample": "the same %d streams on nproc = %d threads, %.2f s wall (best of 2)" % (ns, nall, cdta)},
         "host": info,
     }
     verified = 0
@@ -323,18 +323,30 @@ def main():
             del d_in, host
             torch.cuda.empty_cache()
             res["extra"] = extra_legs(args, env)
+    # Teardown.  A collective that never completes cannot be cancelled, only left behind: the line still goes out, it
+    # says what was abandoned, and the process then ends with kExitAbandoned instead of 0 so that the launcher's exit
+    # code shows what the line's c_abi_error / teardown fields say.
+    abandoned = bool(env.get("hard_exit"))
+    teardown = {}
+    if dist is not None and not abandoned:
+        ok, _ = run_with_time_limit(lambda: dist.barrier(), env, 120.0)
+        teardown["barrier"] = "ok" if ok else "did not finish within 120 s; left behind"
+        abandoned = not ok
     if rank == 0:
+        if dist is not None:
+            res["teardown"] = dict(teardown, abandoned_collective=abandoned,
+                                   exit_code=kExitAbandoned if abandoned else 0)
         print(json.dumps(res))
         sys.stdout.flush()
-    if dist is not None:
-        # (the line is out: nothing behind it may keep the process alive -- a rank that left a stuck side measurement
-        # behind, or whose peers did, ends hard instead of waiting in a barrier)
-        done = False
-        if not env.get("hard_exit"):
-            done, _ = run_with_time_limit(lambda: (dist.barrier(), dist.destroy_process_group()), env, 120.0)
-        if not done:
-            sys.stderr.flush()
-            os._exit(0)
+    if dist is not None and not abandoned:
+        ok, _ = run_with_time_limit(lambda: dist.destroy_process_group(), env, 60.0)
+        if not ok:
+            sys.stderr.write("bench.py: destroy_process_group did not finish within 60 s; left behind\n")
+            abandoned = True
+    if abandoned:
+        # (no eng.close(): the stuck call may still hold the engine; never restart or exec from here)
+        sys.stderr.flush()
+        os._exit(kExitAbandoned)
     eng.close()
 
 
@@ -556,7 +568,7 @@ def bench_deflate(args, env, host, d_in, in_off, n, blen):
             done, val = run_with_time_limit(native_section, env, float(os.environ.get("FLATE_BENCH_NATIVE_LIMIT_S", "240")))
             if not done:
                 env["hard_exit"] = True
-                gather_info["c_abi_error"] = "the C-ABI exchange did not finish within its time limit; left behind, the process ends with os._exit"
+                gather_info["c_abi_error"] = "the C-ABI exchange did not finish within its time limit; left behind, the process ends with exit code %d" % kExitAbandoned
                 print("bench: " + gather_info["c_abi_error"], file=sys.stderr)
             elif isinstance(val, SystemExit):
                 raise val  # a mismatch ends the run
@@ -665,7 +677,7 @@ def bench_inflate(args, env, d_in, in_off, n, blen, host=None, steps=None, warmu
         from oracle import pyoracle
         ns = min(args.cpu_sample_streams * 2, n)  # the decoder is faster than the encoder
         info = cpu_info()
-        cores = min(info["nproc"], 16)
+        cores = info["usable_cpus"]
         h_off = np.asarray(coff[:ns + 1], dtype=np.uint64)
         h_comp = comp[:int(h_off[-1])].cpu().numpy()
         t1 = time.perf_counter()
@@ -673,19 +685,10 @@ def bench_inflate(args, env, d_in, in_off, n, blen, host=None, steps=None, warmu
         cdt = time.perf_counter() - t1
         if int(o_st.any()) or int((o_len != blen).any()):
             raise SystemExit("oracle inflate failed on the sample")
-        cdta = None
-        for _ in range(2):
-            t1 = time.perf_counter()
-            pyoracle.inflate_batch(h_comp, h_off, [blen] * ns, nthreads=info["nproc"])
-            d = time.perf_counter() - t1
-            cdta = d if cdta is None else min(cdta, d)
         cpu_baseline = {
             "value": round(ns * blen / cdt / 2**30, 4), "unit": "GiB/s", "cores": cores, "kind": "port",
             "sample": "first %d of %d streams (%d MiB out), oracle C restatement, %d threads, %.1f s wall"
                       % (ns, n, ns * blen >> 20, cores, cdt),
-            "all_cores": {"value": round(ns * blen / cdta / 2**30, 4), "unit": "GiB/s", "threads": info["nproc"],
-                          "sample": "the same %d streams on nproc = %d threads, %.2f s wall (best of 2)"
-                                    % (ns, info["nproc"], cdta)},
             "host": info,
         }
     host_leg = None

@@ -77,7 +77,8 @@ void flate_hip_destroy(flate_hip_ctx *ctx);
 int flate_hip_set_stream(flate_hip_ctx *ctx, void *hip_stream);
 /* Tuning knobs of the match finder's launch geometry (results never change):
  *   "guest_blocks"       extra persistent wavefronts whose hash table lives in L2 instead of LDS
- *                        (default 6.5 per CU; 0 = off)
+ *                        (default 6 per CU: 4 LDS-table + 6 guest blocks fill the 128 LDS granules of a
+                        CU; larger values displace LDS-table blocks and are slower; 0 = off)
  *   "resident_blocks"    persistent LDS-table wavefronts (default 4 per CU)
  *   "guest_min_streams"  batches smaller than this use one block per stream (default 5 per CU = 1280)
  *   "window_units"       1 (default): multi-window streams of a persistent launch are scheduled one

@@ -35,16 +35,22 @@ def _hash_files(names):
     return h.hexdigest()[:12]
 
 
-def source_hash():
-    """'all:<h>;lz77:<h>;huff:<h>;inflate:<h>' -- hashes over the sources the library is built from:
+def source_hash(flags_by_source=None):
+    """'all:<h>;lz77:<h>;huff:<h>;inflate:<h>[;flags:<h>]' -- hashes over the sources the library is built from:
     everything, and per kernel family (its own files + the shared headers and the ABI file).
     Compiled into the library (flate_hip_build_id) and written beside every PMC collection in
     profiles/, so that a bench line can tell whether a collected figure describes the kernels it
-    times (a change to the inflater does not stale the match finder's traffic figure)."""
+    times (a change to the inflater does not stale the match finder's traffic figure).  A build with
+    per-source flags (the TEST build, experiment builds) carries a 'flags:' component, so that it never
+    reports the product library's id."""
+    import hashlib
     everything = SOURCES + [h for h in HEADERS]
     parts = ["all:" + _hash_files(everything)]
     for g, files in GROUPS.items():
         parts.append(g + ":" + _hash_files(files + SHARED))
+    if flags_by_source:
+        desc = ";".join("%s=%s" % (k, " ".join(v)) for k, v in sorted(flags_by_source.items()))
+        parts.append("flags:" + hashlib.sha256(desc.encode()).hexdigest()[:8])
     return ";".join(parts)
 
 
@@ -83,7 +89,7 @@ def _compile_objects(hipcc, flags_by_source, verbose):
     os.makedirs(OBJ_DIR, exist_ok=True)
     hdr_hash = _hash_files([h for h in HEADERS])
     base = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
-    build_id = {"flate_api.hip": ["-DFLATE_HIP_BUILD_ID=\"%s\"" % source_hash()]}  # (the one file that reports it)
+    build_id = {"flate_api.hip": ["-DFLATE_HIP_BUILD_ID=\"%s\"" % source_hash(flags_by_source)]}  # (the one file that reports it)
     jobs = []
     for src in SOURCES:
         path = os.path.join(CSRC, src)
@@ -97,11 +103,12 @@ def _compile_objects(hipcc, flags_by_source, verbose):
     def one(job):
         path, obj, flags = job
         if not os.path.exists(obj):
-            cmd = [hipcc] + flags + ["-c", path, "-o", obj + ".tmp"]
+            tmp = "%s.%d.tmp" % (obj, os.getpid())  # (two builders at once never write one file)
+            cmd = [hipcc] + flags + ["-c", path, "-o", tmp]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)
-            os.replace(obj + ".tmp", obj)
+            os.replace(tmp, obj)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
@@ -109,11 +116,12 @@ def _compile_objects(hipcc, flags_by_source, verbose):
 
 
 def _link(hipcc, objs, out, verbose):
-    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", out + ".tmp", "-lpthread", "-ldl"]
+    tmp = "%s.%d.tmp" % (out, os.getpid())
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", tmp, "-lpthread", "-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    os.replace(out + ".tmp", out)
+    os.replace(tmp, out)
 
 
 def build(force=False, verbose=False):

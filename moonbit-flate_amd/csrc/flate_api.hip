@@ -98,6 +98,7 @@ struct flate_hip_ctx {
   // (a poll is one relaxed load + s_sleep, >= 0.4 us; a wave that is not running does not count)
   uint32_t spin_limit = 8u << 20;
   uint32_t inject_drop_push = 0;  // test hook: the k-th window hand-over (1-based) is dropped
+  uint32_t inject_stall = 0;      // test hook: the k-th dense batch (1-based) of every chunk makes no progress
   uint64_t stream_rebase = 1ull << 30;  // flate_hip_stream: origin moved up past this many bytes
   int64_t debug_buffer_reset = 0;       // test hook: buffer_reset (deflate-fast.mbt:55) of streams opened from now on
   hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
@@ -365,6 +366,7 @@ int run_lz77(flate_hip_ctx *c, const uint8_t *d_in, const uint64_t *in_off, cons
   P.gtable_blocks = 0;
   P.spin_limit = c->spin_limit;
   P.inject_drop_push = c->inject_drop_push;
+  P.inject_stall = c->inject_stall;
   P.taken = nullptr;
   P.uq_ready = nullptr;
   P.uq_ctr = nullptr;
@@ -517,12 +519,17 @@ const char *flate_hip_strerror(int code) {
 #endif
 #define FLATE_STR2(x) #x
 #define FLATE_STR(x) FLATE_STR2(x)
+#ifdef FLATE_EXPERIMENT_BUILD  // (a build that may contain FLATE_EXP_* switches: never a measurement's or a product's id)
+#define FLATE_ID_EXP ";exp"
+#else
+#define FLATE_ID_EXP ""
+#endif
 #ifdef FLATE_EXPERIMENT_TABLE_BITS
 const char *flate_hip_build_id(void) {
-  return FLATE_HIP_BUILD_ID ";NOT-BIT-EXACT:table_bits=" FLATE_STR(FLATE_EXPERIMENT_TABLE_BITS);
+  return FLATE_HIP_BUILD_ID FLATE_ID_EXP ";NOT-BIT-EXACT:table_bits=" FLATE_STR(FLATE_EXPERIMENT_TABLE_BITS);
 }
 #else
-const char *flate_hip_build_id(void) { return FLATE_HIP_BUILD_ID; }
+const char *flate_hip_build_id(void) { return FLATE_HIP_BUILD_ID FLATE_ID_EXP; }
 #endif
 
 const char *flate_hip_last_hip_error(const flate_hip_ctx *ctx) {
@@ -682,6 +689,8 @@ int flate_hip_set_option(flate_hip_ctx *c, const char *name, int64_t value) {
     c->stream_rebase = (uint64_t)value;
   } else if (k == "debug_drop_window_push" && value >= 0 && value <= 0x7fffffff) {
     c->inject_drop_push = (uint32_t)value;
+  } else if (k == "debug_stall_batch" && value >= 0 && value <= 0x7fffffff) {
+    c->inject_stall = (uint32_t)value;
   } else if (k == "debug_buffer_reset" && value >= 0 && value <= 0x7fffffff) {
     c->debug_buffer_reset = value;
 
@@ -887,6 +896,10 @@ static int deflate_common(flate_hip_ctx *c, const uint8_t *in, const uint64_t *i
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   ctl_finish(c);
   if (c->h_status_word) {
+    if (c->h_status_word == kStatusNoProgress) {
+      c->hip_err = "a match-finder batch made no progress (the chunk was abandoned)";
+      return FLATE_HIP_E_INTERNAL;
+    }
     if (c->h_status_word == kStatusLanesLost) {
       c->hip_err = "a persistent match-finder loop lost lanes of its wavefront (miscompiled loop?)";
       return FLATE_HIP_E_INTERNAL;
@@ -1212,7 +1225,22 @@ static int deflate_host_pipelined(flate_hip_ctx *c, const uint8_t *in, const uin
   for (auto &w : workers)
     if (w.joinable()) w.join();
   const std::string err = pipe.finish();
-  if (lane_threw) throw std::runtime_error(c->hip_err);  // every thread has ended: the caller falls back to one pass
+  // A lane that threw may sit behind the group the collector stopped at (lane 1 throws in group 3 and raises `stop`
+  // before lane 0 has started group 2: group 2 then carries E_INTERNAL without a message): look at every group.
+  for (uint32_t g = 0; g < G; ++g)
+    if (res[g].threw) {
+      lane_threw = true;
+      if (!res[g].err.empty()) c->hip_err = res[g].err;
+      break;
+    }
+  if (lane_threw) {
+    // the one-pass fallback reuses c->d_in / c->d_out: nothing of the lanes may still be writing there
+    for (int k = 0; k < lanes; ++k) {
+      (void)hipStreamSynchronize(c->lane[k]->stream);
+      if (c->lane[k]->guest_stream) (void)hipStreamSynchronize(c->lane[k]->guest_stream);
+    }
+    throw std::runtime_error(c->hip_err);  // every thread has ended: the caller falls back to one pass
+  }
   if (rc == FLATE_HIP_OK && !err.empty()) rc = FLATE_HIP_E_HIP;
   if (rc == FLATE_HIP_E_HIP && c->hip_err.empty()) c->hip_err = err;
   for (int k = 0; k < FLATE_HIP_STAGE_COUNT; ++k) c->stage_ms[k] = stage_sum[k];

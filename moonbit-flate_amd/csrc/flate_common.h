@@ -14,6 +14,12 @@
 #define FLATE_HD inline
 #endif
 
+// Timing experiments that produce WRONG BYTES on purpose (-DFLATE_EXP_NO_INPUT, -DFLATE_EXP_NO_HISTORY_LOAD) compile
+// only in a build that says what it is: -DFLATE_EXPERIMENT_BUILD, which flate_hip_build_id() reports as ";exp".
+#if (defined(FLATE_EXP_NO_INPUT) || defined(FLATE_EXP_NO_HISTORY_LOAD)) && !defined(FLATE_EXPERIMENT_BUILD)
+#error "FLATE_EXP_* switches corrupt the output on purpose: build them with -DFLATE_EXPERIMENT_BUILD only"
+#endif
+
 namespace flate {
 
 // deflate-fast.mbt:12.  A scaling probe may build the library with another table size

@@ -17,7 +17,8 @@ constexpr int kStatusUqTimeout = -0x1001;    // uq_pop: the unit with my ticket 
 constexpr int kStatusGateTimeout = -0x1002;  // (retired with the overlapped entropy stage; the number stays reserved)
 constexpr int kStatusBadIndex = -0x1003;     // an index outside the scratch it addresses (never expected)
 constexpr int kStatusLanesLost = -0x1004;    // a persistent loop is running without all 64 lanes
-static_assert(kStatusUqTimeout < -64 && kStatusLanesLost > -0x100000, "device-only status words: their own range");
+constexpr int kStatusNoProgress = -0x1005;   // lz77_stream: a batch left the parser where it found it
+static_assert(kStatusUqTimeout < -64 && kStatusNoProgress > -0x100000, "device-only status words: their own range");
 
 struct LzParams {
   const uint8_t *in;
@@ -38,6 +39,7 @@ struct LzParams {
   uint32_t gtable_blocks;  // tables behind `gtables` (a guest block beyond them does nothing)
   uint32_t spin_limit;     // polls before a bounded wait gives up
   uint32_t inject_drop_push;  // test hook (option debug_drop_window_push): drop that hand-over
+  uint32_t inject_stall;      // test hook (option debug_stall_batch): that dense batch of every chunk undoes its progress
   // resumable single-stream launches (flate_hip_stream_write): the stream's first LZ77 window in this
   // launch has absolute index win0 (in / in_off then describe the stream through a virtual base:
   // in + absolute position is valid for the 32 KiB of history and the new bytes); 0 otherwise

@@ -8,8 +8,17 @@
 namespace flate {
 
 constexpr int kDenseKeep = 61;  // keep using a dense batch while the next s-1 lane <= this (58..61 measured: 61 best by 0.8 %)
+// An event that starts at lane 62 or 63 has no scan lane left in its batch: the general path's probe masks would
+// shift by 64 (undefined; the hardware shifts by 0) and the batch ends where it began -- the build with 62 hung its
+// run (profiles/r05/README.md section 9).  The parser's progress guard (kStatusNoProgress) is the second line.
+static_assert(kDenseKeep >= 0 && kDenseKeep <= 61, "an event must start at a lane that leaves it a scan lane (a + 2 <= 63)");
 // multi-window streams: 16-bit modular table slots with periodic sweeps (see lz77_stream)
 constexpr uint32_t kSweepEvery = 8192, kSpanMax = 16384, kMarkerBack = 36864;
+// A sweep at R leaves no slot older than 32768 and writes dead slots as "kMarkerBack behind R".  Until the next sweep a
+// lookup comes from at most R + kSweepEvery + one batch (64 positions dense, kSpanMax sparse): the marker must read as
+// out of range (> 32768) and every distance, the marker's included, must stay below 2^16 to be told apart.
+static_assert(kMarkerBack > 32768u && kSweepEvery + kSpanMax + 64u + kMarkerBack < 65536u && kSpanMax >= 64u,
+              "16-bit modular table slots: sweep period + batch span + marker distance must stay below 2^16");
 
 FLATE_D uint32_t ld32(const uint8_t *p) {
   uint32_t v;

@@ -283,7 +283,18 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
     const uint64_t spec_full =
         (2ull << lane) | (lane + 2 < 64 ? ((0x00000000ffffffffull << (lane + 2)) | (0x5555555500000000ull << (lane + 2)))
                                         : 0ull);
+    // Progress guard: every batch moves the parser (a dense batch raises s or turns sparse, a sparse batch raises
+    // e_idx or finds a match) or ends the chunk.  A batch that leaves all of it where it was would repeat for ever
+    // (the kDenseKeep = 62 build of round 5 did): the chunk is abandoned and the call ends FLATE_HIP_E_INTERNAL.
+    int g_s = -2, g_e = -1;
+    bool g_sp = false;
+    uint32_t g_nb = 0;
     while (!done) {
+      if (s == g_s && e_idx == g_e && sparse == g_sp) {
+        if (lane == 0) atomicExch(P.status, kStatusNoProgress);
+        break;
+      }
+      g_s = s, g_e = e_idx, g_sp = sparse;
       if (!sparse) {
         // =============================== dense batch ===============================
         auto dense_batch = [&](auto interior_tag) {
@@ -620,6 +631,8 @@ FLATE_D void lz77_stream(const LzParams &P, const uint32_t sid, uint16_t *table,
           dense_batch(std::true_type{});
         else
           dense_batch(std::false_type{});
+        // (test hook, option debug_stall_batch: the k-th dense batch of a chunk forgets what it did)
+        if (P.inject_stall != 0 && ++g_nb == P.inject_stall) s = g_s, sparse = false, done = false, pre_valid = false;
       } else {
         // =============================== sparse batch ==============================
         const int e = e_idx + lane;

@@ -168,9 +168,10 @@ def test_bench_line_survives_a_c_abi_exchange_that_hangs():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
                         "--streams", "64", "--stream-len", "4096"],
                        env=env, capture_output=True, text=True, timeout=240)
-    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.returncode == 3, r.stderr[-2000:]  # (bench.kExitAbandoned: the hang shows in the exit code too)
     assert time.time() - t0 < 200
     line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["teardown"]["abandoned_collective"] is True and line["teardown"]["exit_code"] == 3
     g = line["config"]["gather"]
     assert line["n_gpus"] == 2 and line["value"] > 0
     assert "c_abi" not in g and "time limit" in g["c_abi_error"]

@@ -292,6 +292,34 @@ def test_lost_window_handover_is_an_error_not_a_hang(oracle):
         e.close()
 
 
+def test_batch_without_progress_is_an_error_not_a_hang(oracle):
+    # The parser's progress guard: a batch that leaves s, the sparse state and the event index where it
+    # found them would repeat for ever (round 5's kDenseKeep = 62 build did, and hung its box).  The test
+    # hook makes the third dense batch of every chunk forget its progress; the call must come back with
+    # FLATE_HIP_E_INTERNAL and name the guard -- for the LDS-table blocks, the guests and the one-block-
+    # per-stream launch, single- and multi-window -- and the engine must work again afterwards.
+    cases = ((24, 65536, ()), (24, 200000, ()),
+             (24, 65536, (("guest_min_streams", 1), ("guest_blocks", 8), ("resident_blocks", 8))),
+             (24, 200000, (("guest_min_streams", 1), ("guest_blocks", 8), ("resident_blocks", 8))))
+    for n, blen, opts in cases:
+        data = flate.synth("text", n, blen, first_stream=7100)
+        off = flate.uniform_offsets(n, blen)
+        e = flate.FlateEngine(0)
+        try:
+            for k, v in opts:
+                e.set_option(k, v)
+            e.set_option("debug_stall_batch", 3)
+            with pytest.raises(flate.FlateError) as ei:
+                e.deflate_batch(data, off)
+            assert ei.value.code == -8 and "no progress" in str(ei.value), (blen, opts)
+            e.set_option("debug_stall_batch", 0)
+            out, out_off = e.deflate_batch(data, off)
+            for i in range(0, n, 5):
+                assert bytes(out[int(out_off[i]):int(out_off[i + 1])]) == oracle.deflate(data[i * blen:(i + 1) * blen]), i
+        finally:
+            e.close()
+
+
 def test_host_pointer_pipeline_matches_single_pass(oracle):
     # host-pointer calls on large batches are pipelined over groups of streams (option
     # host_pipeline_groups): same bytes and the same index as one pass, and as the oracle
