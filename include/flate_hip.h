@@ -127,7 +127,10 @@ int flate_hip_set_stream(flate_hip_ctx *ctx, void *hip_stream);
  *                        on, so that the reference's shift_offsets can be reached in a few windows
  *                        instead of after 2.1 GB (0 = the reference's value)
  *   "debug_drop_window_push"  test hook: k > 0 loses the k-th window hand-over of the next
- *                        multi-window launch, so that the bounded wait can be exercised */
+ *                        multi-window launch, so that the bounded wait can be exercised
+ *   "debug_stall_batch"  test hook: k > 0 makes the k-th dense batch of every LZ77 window forget its
+ *                        progress, so that the match finder's progress guard can be exercised (the
+ *                        call returns FLATE_HIP_E_INTERNAL, "a match-finder batch made no progress") */
 int flate_hip_set_option(flate_hip_ctx *ctx, const char *name, int64_t value);
 const char *flate_hip_strerror(int code);
 /* Hash of the sources this library was built from (moonbit-flate_amd/build.py: source_hash):
