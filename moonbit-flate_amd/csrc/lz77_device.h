@@ -12,8 +12,21 @@ constexpr int kDenseKeep = 61;  // keep using a dense batch while the next s-1 l
 // shift by 64 (undefined; the hardware shifts by 0) and the batch ends where it began -- the build with 62 hung its
 // run (profiles/r05/README.md section 9).  The parser's progress guard (kStatusNoProgress) is the second line.
 static_assert(kDenseKeep >= 0 && kDenseKeep <= 61, "an event must start at a lane that leaves it a scan lane (a + 2 <= 63)");
-// multi-window streams: 16-bit modular table slots with periodic sweeps (see lz77_stream)
-constexpr uint32_t kSweepEvery = 8192, kSpanMax = 16384, kMarkerBack = 36864;
+// multi-window streams: 16-bit modular table slots with periodic sweeps (see lz77_stream).  The sweep period and the
+// reach of a sparse batch share one budget (the assert below); round 6 moved it from 8192 / 16384 to 20480 / 4096:
+// 2.5 sweeps fewer per 65535-byte window (config 3's match finder 17.69 -> 17.40 ms, profiles/r06/README.md section 4),
+// and a sparse batch reaches 4096 positions only at strides above 64, which one window never gets to
+// (the stride grows by one per 32 probes without a match: 63 at the end of a window of random bytes).
+#ifndef FLATE_LZ_SWEEP_EVERY  // (A/B builds: tools/build_variant.sh ... -DFLATE_LZ_SWEEP_EVERY=.. -DFLATE_LZ_SPAN_MAX=.. -DFLATE_LZ_MARKER_BACK=..)
+#define FLATE_LZ_SWEEP_EVERY 20480
+#endif
+#ifndef FLATE_LZ_SPAN_MAX
+#define FLATE_LZ_SPAN_MAX 4096
+#endif
+#ifndef FLATE_LZ_MARKER_BACK
+#define FLATE_LZ_MARKER_BACK 36864
+#endif
+constexpr uint32_t kSweepEvery = FLATE_LZ_SWEEP_EVERY, kSpanMax = FLATE_LZ_SPAN_MAX, kMarkerBack = FLATE_LZ_MARKER_BACK;
 // A sweep at R leaves no slot older than 32768 and writes dead slots as "kMarkerBack behind R".  Until the next sweep a
 // lookup comes from at most R + kSweepEvery + one batch (64 positions dense, kSpanMax sparse): the marker must read as
 // out of range (> 32768) and every distance, the marker's included, must stay below 2^16 to be told apart.
