@@ -29,7 +29,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/$tag/stats_c3 -
 # fabric traffic of the match finder AT THE QUEUE SPLIT OF THE HEADLINE RUN ABOVE (the guests' share moves the figure)
 K=${FLATE_TRAFFIC_SPLIT:-$(python3 -c "import json;d=json.loads(open('gpurun_out/$tag/bench.json').read().strip().splitlines()[-1]);print(d['config']['lz77_streams_by_kernel']['lds_table_blocks'])")}
 FLATE_TRAFFIC_SPLIT=$K tools/traffic_collect.sh ${tag}_c2 16384 65536 > gpurun_out/$tag/traffic_c2.json 2> gpurun_out/$tag/traffic_c2.err
-tools/traffic_collect.sh ${tag}_c3 4096 262144 "--option window_units=0" > gpurun_out/$tag/traffic_c3.json 2> gpurun_out/$tag/traffic_c3.err
+env -u FLATE_TRAFFIC_SPLIT tools/traffic_collect.sh ${tag}_c3 4096 262144 "--option window_units=0" > gpurun_out/$tag/traffic_c3.json 2> gpurun_out/$tag/traffic_c3.err
 tools/inflate_traffic.sh ${tag}_inf > gpurun_out/$tag/traffic_inflate.json 2> gpurun_out/$tag/traffic_inflate.err
 tools/inflate_traffic.sh ${tag}_inf16k 16384 > gpurun_out/$tag/traffic_inflate_16k.json 2> gpurun_out/$tag/traffic_inflate_16k.err
 # (the crossover sweep takes minutes of its own: FLATE_COLLECT_CROSSOVER=1, or run tools/inflate_crossover.py in a call of its own)
