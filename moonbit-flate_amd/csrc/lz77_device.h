@@ -15,8 +15,9 @@ static_assert(kDenseKeep >= 0 && kDenseKeep <= 61, "an event must start at a lan
 // multi-window streams: 16-bit modular table slots with periodic sweeps (see lz77_stream).  The sweep period and the
 // reach of a sparse batch share one budget (the assert below); round 6 moved it from 8192 / 16384 to 20480 / 4096:
 // 2.5 sweeps fewer per 65535-byte window (config 3's match finder 17.69 -> 17.40 ms, profiles/r06/README.md section 4),
-// and a sparse batch reaches 4096 positions only at strides above 64, which one window never gets to
-// (the stride grows by one per 32 probes without a match: 63 at the end of a window of random bytes).
+// and what the smaller reach costs is a few batches on incompressible windows only: the stride of a scan without a match
+// is about (positions scanned) / 32 (deflate-fast.mbt:178-187), so beyond 2048 such positions a sparse batch holds
+// 4096 / stride events instead of 64 -- about 15 more batches in a window of random bytes, which takes ~300 probes in all.
 #ifndef FLATE_LZ_SWEEP_EVERY  // (A/B builds: tools/build_variant.sh ... -DFLATE_LZ_SWEEP_EVERY=.. -DFLATE_LZ_SPAN_MAX=.. -DFLATE_LZ_MARKER_BACK=..)
 #define FLATE_LZ_SWEEP_EVERY 20480
 #endif
