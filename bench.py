@@ -328,10 +328,18 @@ def main():
     # code shows what the line's c_abi_error / teardown fields say.
     abandoned = bool(env.get("hard_exit"))
     teardown = {}
+    limit = float(os.environ.get("FLATE_BENCH_TEARDOWN_LIMIT_S", "120"))
+    if env.get("test_engine") and os.environ.get("FLATE_TEST_LATE_TEARDOWN_RANK") == str(rank):
+        time.sleep(float(os.environ.get("FLATE_TEST_LATE_TEARDOWN_S", "10")))  # (tests: a peer that reaches the barrier too late)
     if dist is not None and not abandoned:
-        ok, _ = run_with_time_limit(lambda: dist.barrier(), env, 120.0)
-        teardown["barrier"] = "ok" if ok else "did not finish within 120 s; left behind"
-        abandoned = not ok
+        ok, r = run_with_time_limit(lambda: dist.barrier(), env, limit)
+        if not ok:
+            teardown["barrier"] = "did not finish within %g s; left behind" % limit
+        elif isinstance(r, BaseException):  # (a peer that is gone: the collective fails instead of hanging)
+            teardown["barrier"] = "raised %s: %s" % (type(r).__name__, str(r)[:200])
+        else:
+            teardown["barrier"] = "ok"
+        abandoned = teardown["barrier"] != "ok"
     if rank == 0:
         if dist is not None:
             res["teardown"] = dict(teardown, abandoned_collective=abandoned,
@@ -339,9 +347,9 @@ def main():
         print(json.dumps(res))
         sys.stdout.flush()
     if dist is not None and not abandoned:
-        ok, _ = run_with_time_limit(lambda: dist.destroy_process_group(), env, 60.0)
-        if not ok:
-            sys.stderr.write("bench.py: destroy_process_group did not finish within 60 s; left behind\n")
+        ok, r = run_with_time_limit(lambda: dist.destroy_process_group(), env, min(limit, 60.0))
+        if not ok or isinstance(r, BaseException):
+            sys.stderr.write("bench.py: destroy_process_group %s\n" % ("did not finish in time; left behind" if not ok else "raised %r" % (r,)))
             abandoned = True
     if abandoned:
         # (no eng.close(): the stuck call may still hold the engine; never restart or exec from here)

@@ -175,3 +175,26 @@ def test_bench_line_survives_a_c_abi_exchange_that_hangs():
     g = line["config"]["gather"]
     assert line["n_gpus"] == 2 and line["value"] > 0
     assert "c_abi" not in g and "time limit" in g["c_abi_error"]
+
+
+def test_bench_teardown_that_hangs_shows_in_the_line_and_in_the_exit_code():
+    """A rank whose peer does not reach the final barrier in time gives up at its limit: rank 0's line is out, its
+    `teardown` field says what was abandoned, and the launcher's exit code is bench.kExitAbandoned -- a hang at
+    teardown no longer reads as rc 0."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["FLATE_BENCH_TEST_ENGINE"] = "tests.cpu_engine:OracleEngine"
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    env["FLATE_TEST_LATE_TEARDOWN_RANK"] = "1"
+    env["FLATE_TEST_LATE_TEARDOWN_S"] = "12"
+    env["FLATE_BENCH_TEARDOWN_LIMIT_S"] = "3"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--streams", "64", "--stream-len", "4096", "--no-native-gather"],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    assert line["teardown"]["abandoned_collective"] is True and "did not finish" in line["teardown"]["barrier"]
